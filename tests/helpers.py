@@ -1,0 +1,33 @@
+"""Shared test helpers: seeded synthetic states in the reference's layouts, golden-fixture loading."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_files(pattern="g2_*.npz"):
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, pattern)))
+
+
+def load_golden(path):
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def make_case(rng, shapes, n_a, cluster, shape=None):
+    """One env: rotated/offset target shape + agents either scattered over the arena or clustered on the
+    shape (the latter exercises in-shape flags, the occupied-cell filter, collisions)."""
+    s = int(rng.integers(0, len(shapes["l_cell"]))) if shape is None else shape
+    g = shapes["grid_coords"][s].T.copy()
+    l_cell = float(shapes["l_cell"][s])
+    th = rng.uniform(-np.pi, np.pi)
+    rot = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+    g = np.ascontiguousarray(rot @ g + rng.uniform(-1.4, 1.4, (2, 1)))
+    if cluster:
+        p = g[:, rng.integers(0, g.shape[1], n_a)] + rng.normal(0, 0.05, (2, n_a))
+    else:
+        p = rng.uniform(-2.4, 2.4, (2, n_a))
+    dp = rng.uniform(-0.5, 0.5, (2, n_a))
+    return np.ascontiguousarray(p), np.ascontiguousarray(dp), g, l_cell
