@@ -1,0 +1,166 @@
+/*
+ * swarm_env.h -- C ABI of libswarmenv.so: the MI355X-native batched AssemblySwarm environment step.
+ *
+ * This is the drop-in boundary for the reference's env-step hot path.  The reference crosses its
+ * Python -> native boundary with ctypes into libAssemblyEnv.so
+ * (/root/reference/cus_gym/gym/envs/customized_envs/envs_cplus/c_lib.py:11-37), five times per step, one
+ * environment at a time, from AssemblySwarmEnv.step()/_get_obs()/_get_reward()
+ * (/root/reference/cus_gym/gym/envs/customized_envs/assembly.py:234-255,357-380,460-466,495-504,613-624).
+ * Here the same Python host binds ONE handle-based library with ctypes; state lives in HBM and one
+ * call advances E independent environments.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) the batched ABI (swarm_*): opaque handle, plain pointers and sizes, int status returns.
+ *      It replaces, fused into one launch per step, what the reference spreads over
+ *        - AssemblySwarmEnv.step numpy glue             assembly.py:487-666 (incl. _get_dist_b2b :442-457)
+ *        - _sf_b2b_all                                  AssemblyEnv.h:64-73   / AssemblyEnv.cpp:735-815
+ *        - _get_dist_b2w                                AssemblyEnv.h:75-81   / AssemblyEnv.cpp:817-855
+ *        - calculateActionPrior / robotPolicy           AssemblyEnv.h:98-109  / AssemblyEnv.cpp:1061-1196
+ *        - _get_observation (+_get_focused, _get_target_grid_state, _make_periodic)
+ *                                                       AssemblyEnv.h:13-34   / AssemblyEnv.cpp:18-351,628-732,858-908
+ *        - _get_reward (+_rho_cos_dec)                  AssemblyEnv.h:35-58   / AssemblyEnv.cpp:354-626,1012-1020
+ *
+ *  (2) the legacy symbols (_get_observation, _get_reward, _sf_b2b_all, _get_dist_b2w,
+ *      calculateActionPrior) with the reference's exact signatures and host-pointer / caller-owned
+ *      buffer contract, so an unmodified assembly.py can load this library in place of
+ *      libAssemblyEnv.so.  They run the same HIP kernels on a private one-environment handle.
+ *
+ * There is no CPU fallback anywhere in this library: without a HIP device every call fails.
+ *
+ * Memory contract of the batched ABI: every pointer passed to swarm_step / swarm_observe /
+ * swarm_get_indices is a DEVICE pointer (hipMalloc / torch.Tensor.data_ptr()) valid on the handle's
+ * device; the calls are asynchronous on the handle's stream (swarm_set_stream).  swarm_set_cells /
+ * swarm_set_state / swarm_get_state accept host or device pointers (hipMemcpyDefault).
+ *
+ * Layouts (E = n_env, N = n_agents, D = obs_dim = 4*(topo + 1 + with_self) + 2*num_obs_grid_max):
+ *   p, dp            double [E][2][N]     component-major per env, exactly the reference's (2, n_a) arrays
+ *   cells            double [E][2][n_cells_max]  the reference's grid_center (2, n_g), row stride n_cells_max
+ *   action           float|double [E][N][2]      agent-major pairs (u_x, u_y)
+ *   obs              float|double [E][N][D]      one contiguous row per agent; row content and order are the
+ *                                                reference's obs column (AssemblyEnv.cpp:294-306)
+ *   reward           float  [E][N]    in {0,1}
+ *   done             uint8  [E][N]    always 0 (assembly.py:480-482)
+ *   a_prior          float|double [E][N][2]
+ *   neighbor_index   int32  [E][N][topo], in_flags int32 [E][N], sensed_index int32 [E][N][num_obs_grid_max],
+ *   occupied_index   int32  [E][N][num_occupied_grid_max]   (the reference's index scratch; debug export)
+ * All arithmetic that decides an index, a flag, the state update or the reward is IEEE double in the
+ * reference's operation order (no FMA contraction); obs / a_prior are rounded once to obs_dtype at the store.
+ */
+#ifndef SWARM_ENV_H
+#define SWARM_ENV_H
+
+#include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWARM_ABI_VERSION 1
+
+enum { SWARM_F32 = 0, SWARM_F64 = 1 };
+
+enum {
+    SWARM_OK = 0,
+    SWARM_ERR_INVALID = 1,      /* bad argument / unsupported configuration */
+    SWARM_ERR_HIP = 2,          /* a HIP runtime call failed (no device, OOM, launch failure ...) */
+    SWARM_ERR_STATE = 3         /* call order violated (e.g. step before cells/state were set) */
+};
+
+typedef struct swarm_env swarm_env_t;
+
+/* Mirrors the constants AssemblySwarmEnv hard-codes or derives (assembly.py:27-81,99-131,193-199). */
+typedef struct swarm_config {
+    int32_t n_env;                  /* E >= 1 */
+    int32_t n_agents;               /* N in [1, 256] */
+    int32_t n_cells_max;            /* capacity of one env's cell list, >= every n_g, <= 32767 */
+    int32_t topo_nei_max;           /* assembly.py:34   = 6 (1..6) */
+    int32_t num_obs_grid_max;       /* assembly.py:128  = 80 */
+    int32_t num_occupied_grid_max;  /* assembly.py:130  = 200 */
+    int32_t is_boundary;            /* 1 = walls (assembly.py:99-103), 0 = periodic */
+    int32_t with_self_state;        /* is_con_self_state */
+    int32_t with_prior;             /* training_method == 'llm_rl': compute a_prior (assembly.py:605-624) */
+    int32_t obs_dtype;              /* SWARM_F32 (product) or SWARM_F64 (bit-exact parity mode) */
+    int32_t device;                 /* HIP device ordinal, -1 = current */
+    int32_t reserved;
+    double d_sen;                   /* assembly.py:199  = 0.4 */
+    double r_avoid;                 /* assembly.py:124 */
+    double size_a;                  /* assembly.py:44   = 0.035 */
+    double k_ball, k_wall, c_wall;  /* assembly.py:71-74 = 30, 100, 5 */
+    double vel_max;                 /* assembly.py:52   = 0.8 */
+    double dt;                      /* assembly.py:79   = 0.1 */
+    double boundary[4];             /* [x_min, y_max, x_max, y_min], assembly.py:193-196 */
+} swarm_config_t;
+
+int  swarm_abi_version(void);
+void swarm_default_config(swarm_config_t *cfg);     /* fills the reference's constants; caller sets sizes */
+
+int  swarm_create(const swarm_config_t *cfg, swarm_env_t **out);
+int  swarm_destroy(swarm_env_t *h);
+/* Message of the last failing call on `h`; h == NULL: last failing swarm_create on this thread. */
+const char *swarm_last_error(const swarm_env_t *h);
+
+int  swarm_set_stream(swarm_env_t *h, void *hip_stream);   /* hipStream_t; NULL = default stream */
+int  swarm_synchronize(swarm_env_t *h);
+int  swarm_obs_dim(const swarm_env_t *h);
+
+/* Target cells of envs [env_begin, env_begin+count): cells[count][2][n_cells_max] (host or device),
+ * n_g[count], l_cell[count] (HOST arrays; l_cell feeds the in-shape threshold sqrt(2)*l_cell/2). */
+int  swarm_set_cells(swarm_env_t *h, int env_begin, int count,
+                     const double *cells, const int32_t *n_g, const double *l_cell);
+int  swarm_set_state(swarm_env_t *h, const double *p, const double *dp);   /* [E][2][N], host or device */
+int  swarm_get_state(swarm_env_t *h, double *p, double *dp);
+
+/* Recompute observations and the obs-derived caches (neighbor_index, in_flags, nearest cell) from the
+ * current state: what AssemblySwarmEnv.reset() does with its final _get_obs() (assembly.py:221).
+ * Must be called after swarm_set_state / swarm_set_cells and before swarm_step.  obs may be NULL. */
+int  swarm_observe(swarm_env_t *h, void *obs);
+
+/* One AssemblySwarmEnv.step(a) for every env.  action_dtype: SWARM_F32 / SWARM_F64.
+ * reward / done / a_prior may be NULL (not written). */
+int  swarm_step(swarm_env_t *h, const void *action, int action_dtype,
+                void *obs, float *reward, uint8_t *done, void *a_prior);
+
+/* Index scratch of the LAST swarm_observe/swarm_step (device pointers, any may be NULL).  The first
+ * call that asks for sensed/occupied indices allocates the export buffers and re-runs the observation
+ * pass on the current state to fill them. */
+int  swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flags,
+                       int32_t *sensed_index, int32_t *occupied_index);
+
+/* Roofline helper: algorithmic bytes one swarm_step moves (SURVEY.md section 8d accounting). */
+double swarm_step_algorithmic_bytes(const swarm_env_t *h);
+/* Time the last N launches?  No: timing lives in the caller (HIP events on the handle's stream).
+ * These two record / read HIP events on that stream so a ctypes host needs no HIP binding. */
+int  swarm_timer_start(swarm_env_t *h);
+int  swarm_timer_stop(swarm_env_t *h, float *elapsed_ms);   /* synchronizes on the stop event */
+
+/* ---- legacy symbols: exact reference signatures (AssemblyEnv.h:13-34,35-58,64-73,75-81,98-109) ---- */
+void _get_observation(double *p_input, double *dp_input, double *heading_input, double *obs_input,
+                      double *boundary_pos_input, double *grid_center_input, int *neighbor_index_input,
+                      int *in_flags_input, int *sensed_index_input, int *occupied_index_input,
+                      double d_sen, double r_avoid, double l_cell, double Vel_max, int topo_nei_max,
+                      int num_obs_grid_max, int num_occupied_grid_max, int n_a, int n_g,
+                      int obs_dim_agent, int dim, bool *condition);
+void _get_reward(double *p_input, double *dp_input, double *heading_input, double *act_input,
+                 double *reward_input, double *boundary_pos_input, double *grid_center_input,
+                 int *neighbor_index_input, int *in_flags_input, int *sensed_index_input,
+                 int *occupied_index_input, double d_sen, double r_avoid, double l_cell,
+                 int topo_nei_max, int num_obs_grid_max, int num_occupied_grid_max, int n_a, int n_g,
+                 int dim, bool *condition, bool *is_collide_b2b_input, bool *is_collide_b2w_input,
+                 double *coefficients);
+void _sf_b2b_all(double *p_input, double *sf_b2b_input, double *d_b2b_edge_input,
+                 bool *is_collide_b2b_input, double *boundary_pos_input, double *d_b2b_center_input,
+                 int n_a, int dim, double k_ball, bool is_periodic);
+void _get_dist_b2w(double *p_input, double *r_input, double *d_b2w_input, bool *isCollision_input,
+                   int dim, int n_a, double *boundary_pos);
+void calculateActionPrior(double *p_input, double *dp_input, double *a_prior_input,
+                          double *grid_center_input, int *neighbor_index_input, double d_sen,
+                          double r_avoid, double l_cell, int topo_nei_max, int n_a, int n_g, int dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWARM_ENV_H */

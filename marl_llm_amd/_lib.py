@@ -1,0 +1,71 @@
+"""ctypes binding of libswarmenv.so (include/swarm_env.h).  No fallback: if the library is missing or
+no HIP device is present, every use fails loudly."""
+import ctypes
+import os
+
+from .build import LIB
+
+F32, F64 = 0, 1
+
+
+class SwarmConfig(ctypes.Structure):
+    _fields_ = [("n_env", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("n_cells_max", ctypes.c_int32),
+                ("topo_nei_max", ctypes.c_int32), ("num_obs_grid_max", ctypes.c_int32),
+                ("num_occupied_grid_max", ctypes.c_int32), ("is_boundary", ctypes.c_int32),
+                ("with_self_state", ctypes.c_int32), ("with_prior", ctypes.c_int32), ("obs_dtype", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("d_sen", ctypes.c_double), ("r_avoid", ctypes.c_double), ("size_a", ctypes.c_double),
+                ("k_ball", ctypes.c_double), ("k_wall", ctypes.c_double), ("c_wall", ctypes.c_double),
+                ("vel_max", ctypes.c_double), ("dt", ctypes.c_double), ("boundary", ctypes.c_double * 4)]
+
+
+class SwarmError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", "swarm_destroy", "swarm_last_error",
+                   "swarm_set_stream", "swarm_synchronize", "swarm_obs_dim", "swarm_set_cells", "swarm_set_state",
+                   "swarm_get_state", "swarm_observe", "swarm_step", "swarm_get_indices",
+                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop")
+LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior")
+
+
+def load():
+    """Load libswarmenv.so (built in-tree by marl_llm_amd.build / __graft_entry__.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB):
+        raise SwarmError(f"{LIB} not found: build it with `python -m marl_llm_amd.build` "
+                         "(there is no CPU fallback for the env step)")
+    lib = ctypes.CDLL(LIB)
+    vp, i32, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.swarm_abi_version.restype = i32
+    lib.swarm_default_config.argtypes = [ctypes.POINTER(SwarmConfig)]; lib.swarm_default_config.restype = None
+    lib.swarm_create.argtypes = [ctypes.POINTER(SwarmConfig), ctypes.POINTER(vp)]; lib.swarm_create.restype = i32
+    lib.swarm_destroy.argtypes = [vp]; lib.swarm_destroy.restype = i32
+    lib.swarm_last_error.argtypes = [vp]; lib.swarm_last_error.restype = ctypes.c_char_p
+    lib.swarm_set_stream.argtypes = [vp, vp]; lib.swarm_set_stream.restype = i32
+    lib.swarm_synchronize.argtypes = [vp]; lib.swarm_synchronize.restype = i32
+    lib.swarm_obs_dim.argtypes = [vp]; lib.swarm_obs_dim.restype = i32
+    lib.swarm_set_cells.argtypes = [vp, i32, i32, vp, vp, vp]; lib.swarm_set_cells.restype = i32
+    lib.swarm_set_state.argtypes = [vp, vp, vp]; lib.swarm_set_state.restype = i32
+    lib.swarm_get_state.argtypes = [vp, vp, vp]; lib.swarm_get_state.restype = i32
+    lib.swarm_observe.argtypes = [vp, vp]; lib.swarm_observe.restype = i32
+    lib.swarm_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]; lib.swarm_step.restype = i32
+    lib.swarm_get_indices.argtypes = [vp, vp, vp, vp, vp]; lib.swarm_get_indices.restype = i32
+    lib.swarm_step_algorithmic_bytes.argtypes = [vp]; lib.swarm_step_algorithmic_bytes.restype = dbl
+    lib.swarm_timer_start.argtypes = [vp]; lib.swarm_timer_start.restype = i32
+    lib.swarm_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]; lib.swarm_timer_stop.restype = i32
+    if lib.swarm_abi_version() != 1:
+        raise SwarmError("libswarmenv.so ABI version mismatch; rebuild")
+    _LIB = lib
+    return lib
+
+
+def check(lib, handle, rc):
+    if rc != 0:
+        msg = lib.swarm_last_error(handle)
+        raise SwarmError(f"libswarmenv error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,174 @@
+"""SwarmBatch: thin torch-facing wrapper around one libswarmenv handle (one GPU, E environments).
+
+Device memory, streams and tensors come from PyTorch-ROCm; all compute is in the HIP library.
+Layouts are the ones documented in include/swarm_env.h.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, F64, SwarmConfig, SwarmError, check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class SwarmBatch:
+    def __init__(self, n_env, n_agents, n_cells_max, r_avoid, *, is_boundary=True, with_self=True, with_prior=True,
+                 obs_dtype=torch.float32, device="cuda:0", d_sen=0.4, topo=6, g_max=80, occ_max=200,
+                 boundary=(-2.4, 2.4, 2.4, -2.4), size_a=0.035, k_ball=30.0, k_wall=100.0, c_wall=5.0,
+                 vel_max=0.8, dt=0.1):
+        if not torch.cuda.is_available():
+            raise SwarmError("no HIP device visible to PyTorch: the env step has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise SwarmError("SwarmBatch needs a cuda (HIP) device")
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        cfg = SwarmConfig()
+        self.lib.swarm_default_config(ctypes.byref(cfg))
+        cfg.n_env, cfg.n_agents, cfg.n_cells_max = int(n_env), int(n_agents), int(n_cells_max)
+        cfg.topo_nei_max, cfg.num_obs_grid_max, cfg.num_occupied_grid_max = int(topo), int(g_max), int(occ_max)
+        cfg.is_boundary, cfg.with_self_state, cfg.with_prior = int(bool(is_boundary)), int(bool(with_self)), int(bool(with_prior))
+        if obs_dtype not in (torch.float32, torch.float64):
+            raise SwarmError("obs_dtype must be torch.float32 or torch.float64")
+        cfg.obs_dtype = F64 if obs_dtype == torch.float64 else F32
+        cfg.device = dev_index
+        cfg.d_sen, cfg.r_avoid, cfg.size_a = float(d_sen), float(r_avoid), float(size_a)
+        cfg.k_ball, cfg.k_wall, cfg.c_wall, cfg.vel_max, cfg.dt = float(k_ball), float(k_wall), float(c_wall), float(vel_max), float(dt)
+        for k in range(4):
+            cfg.boundary[k] = float(boundary[k])
+        self.cfg = cfg
+        self.handle = ctypes.c_void_p()
+        rc = self.lib.swarm_create(ctypes.byref(cfg), ctypes.byref(self.handle))
+        if rc != 0:
+            raise SwarmError(f"swarm_create failed ({rc}): {self.lib.swarm_last_error(None).decode()}")
+        self.n_env, self.n_agents, self.n_cells_max = int(n_env), int(n_agents), int(n_cells_max)
+        self.topo, self.g_max, self.occ_max = int(topo), int(g_max), int(occ_max)
+        self.obs_dtype = obs_dtype
+        self.with_prior = bool(with_prior)
+        self.obs_dim = self.lib.swarm_obs_dim(self.handle)
+        E, N, D = self.n_env, self.n_agents, self.obs_dim
+        # ping-pong output buffers: the previous step's tensors stay valid for one more step
+        self._obs = [torch.empty((E, N, D), dtype=obs_dtype, device=self.device) for _ in range(2)]
+        self._rew = [torch.empty((E, N), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._pri = [torch.empty((E, N, 2), dtype=obs_dtype, device=self.device) for _ in range(2)]
+        self._done = torch.zeros((E, N), dtype=torch.uint8, device=self.device)
+        self._flip = 0
+
+    # -- plumbing -----------------------------------------------------------------------------------
+    def _sync_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib, self.handle, self.lib.swarm_set_stream(self.handle, ctypes.c_void_p(s)))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.swarm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup --------------------------------------------------------------------------------------
+    def set_cells(self, cells, n_g, l_cell, env_begin=0):
+        """cells [count, 2, n_cells_max] float64 (numpy or torch, host or device); n_g, l_cell [count] (host)."""
+        n_g = np.ascontiguousarray(n_g, dtype=np.int32)
+        l_cell = np.ascontiguousarray(l_cell, dtype=np.float64)
+        count = int(n_g.shape[0])
+        if isinstance(cells, torch.Tensor):
+            c = cells.to(dtype=torch.float64).contiguous()
+            if tuple(c.shape) != (count, 2, self.n_cells_max):
+                raise SwarmError(f"cells must be [{count}, 2, {self.n_cells_max}]")
+            cptr = _ptr(c)
+        else:
+            c = np.ascontiguousarray(cells, dtype=np.float64)
+            if c.shape != (count, 2, self.n_cells_max):
+                raise SwarmError(f"cells must be [{count}, 2, {self.n_cells_max}]")
+            cptr = c.ctypes.data_as(ctypes.c_void_p)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_set_cells(self.handle, int(env_begin), count, cptr,
+                                                              n_g.ctypes.data_as(ctypes.c_void_p),
+                                                              l_cell.ctypes.data_as(ctypes.c_void_p)))
+
+    def set_state(self, p, dp):
+        """p, dp [E, 2, N] float64 (numpy or torch)."""
+        keep = []
+        ptrs = []
+        for a in (p, dp):
+            if isinstance(a, torch.Tensor):
+                t = a.to(dtype=torch.float64).contiguous()
+                shape = tuple(t.shape); ptrs.append(_ptr(t))
+            else:
+                t = np.ascontiguousarray(a, dtype=np.float64)
+                shape = t.shape; ptrs.append(t.ctypes.data_as(ctypes.c_void_p))
+            if shape != (self.n_env, 2, self.n_agents):
+                raise SwarmError(f"state arrays must be [{self.n_env}, 2, {self.n_agents}]")
+            keep.append(t)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_set_state(self.handle, ptrs[0], ptrs[1]))
+
+    def get_state(self):
+        p = torch.empty((self.n_env, 2, self.n_agents), dtype=torch.float64, device=self.device)
+        dp = torch.empty_like(p)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_get_state(self.handle, _ptr(p), _ptr(dp)))
+        return p, dp
+
+    # -- hot path -----------------------------------------------------------------------------------
+    def observe(self):
+        """Recompute obs + caches from the current state (the tail of the reference's reset())."""
+        self._flip ^= 1
+        obs = self._obs[self._flip]
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_observe(self.handle, _ptr(obs)))
+        return obs
+
+    def step(self, action):
+        """action [E, N, 2] float32/float64 device tensor -> (obs [E,N,D], reward [E,N], done [E,N] uint8,
+        a_prior [E,N,2] or None).  Asynchronous on torch's current stream."""
+        if not isinstance(action, torch.Tensor) or action.device != self.device:
+            raise SwarmError("action must be a torch tensor on the env's device")
+        if tuple(action.shape) != (self.n_env, self.n_agents, 2):
+            raise SwarmError(f"action must be [{self.n_env}, {self.n_agents}, 2]")
+        if action.dtype not in (torch.float32, torch.float64):
+            action = action.to(torch.float32)
+        action = action.contiguous()
+        self._flip ^= 1
+        f = self._flip
+        self._sync_stream()
+        check(self.lib, self.handle,
+              self.lib.swarm_step(self.handle, _ptr(action), F64 if action.dtype == torch.float64 else F32,
+                                  _ptr(self._obs[f]), _ptr(self._rew[f]), _ptr(self._done),
+                                  _ptr(self._pri[f]) if self.with_prior else None))
+        return self._obs[f], self._rew[f], self._done, (self._pri[f] if self.with_prior else None)
+
+    def indices(self, sensed=True, occupied=True):
+        """The reference's index scratch for the current state (debug / parity export)."""
+        E, N = self.n_env, self.n_agents
+        nei = torch.empty((E, N, self.topo), dtype=torch.int32, device=self.device)
+        inf = torch.empty((E, N), dtype=torch.int32, device=self.device)
+        sen = torch.empty((E, N, self.g_max), dtype=torch.int32, device=self.device) if sensed else None
+        occ = torch.empty((E, N, self.occ_max), dtype=torch.int32, device=self.device) if occupied else None
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_get_indices(self.handle, _ptr(nei), _ptr(inf), _ptr(sen), _ptr(occ)))
+        return dict(neighbor_index=nei, in_flags=inf, sensed_index=sen, occupied_index=occ)
+
+    # -- measurement helpers --------------------------------------------------------------------------
+    def algorithmic_bytes_per_step(self):
+        return float(self.lib.swarm_step_algorithmic_bytes(self.handle))
+
+    def timer_start(self):
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(self.lib, self.handle, self.lib.swarm_timer_stop(self.handle, ctypes.byref(ms)))
+        return float(ms.value)

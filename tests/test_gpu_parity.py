@@ -1,0 +1,231 @@
+"""GPU parity tests: the HIP path (through the C ABI, via marl_llm_amd.batched.SwarmBatch) against the oracle
+(oracle/assembly_oracle.c) and against the golden vectors recorded from the reference.
+
+Tolerances, stated once:
+  * state (p, dp), every index / flag array, done and reward: BIT-EXACT (==).
+  * obs / a_prior with obs_dtype=float64: BIT-EXACT.
+  * obs / a_prior with obs_dtype=float32 (the product dtype): equal to the oracle's double value rounded once to
+    float32 -- i.e. exact equality after casting the oracle's output to float32 (|err| <= 2^-24 relative).
+  The only outputs that touch a non-correctly-rounded primitive are the reward's cos() terms (device libm vs
+  glibc, <= a few ulp); a flip of the 0.05 threshold from that has probability ~1e-14 per agent-step.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN_DIR, golden_files, load_golden, make_case
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _batch(**kw):
+    from marl_llm_amd.batched import SwarmBatch
+    return SwarmBatch(**kw)
+
+
+def _to_rows(obs_cols):
+    """oracle obs (D, N) -> rows (N, D)."""
+    return np.ascontiguousarray(obs_cols.T)
+
+
+def _pad_cells(grids, ng_max):
+    E = len(grids)
+    cells = np.zeros((E, 2, ng_max))
+    n_g = np.zeros(E, np.int32)
+    for e, g in enumerate(grids):
+        n_g[e] = g.shape[1]
+        cells[e, :, : g.shape[1]] = g
+    return cells, n_g
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=os.path.basename)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_golden_steps(path, dtype):
+    """Every recorded reference step, teacher-forced through the HIP path (E = 1)."""
+    z = load_golden(path)
+    T, _, n_a = z["p"].shape
+    n_g = z["grid"].shape[1]
+    odt = torch.float64 if dtype == "f64" else torch.float32
+    sb = _batch(n_env=1, n_agents=n_a, n_cells_max=n_g, r_avoid=float(z["r_avoid"]), d_sen=float(z["d_sen"]),
+                is_boundary=bool(z["is_boundary"]), with_self=bool(z["with_self"]), obs_dtype=odt,
+                boundary=tuple(z["boundary"]))
+    sb.set_cells(z["grid"][None], [n_g], [float(z["l_cell"])])
+    for t in range(T):
+        sb.set_state(z["p"][t][None], z["dp"][t][None])
+        sb.observe()
+        assert np.array_equal(sb.indices(False, False)["neighbor_index"][0].cpu().numpy(), z["nei_prev"][t])
+        act = torch.from_numpy(np.ascontiguousarray(z["a"][t].T)[None]).to(sb.device)       # (2,N) -> [1,N,2]
+        obs, rew, done, pri = sb.step(act)
+        p, dp = sb.get_state()
+        assert np.array_equal(p[0].cpu().numpy(), z["p_next"][t])
+        assert np.array_equal(dp[0].cpu().numpy(), z["dp_next"][t])
+        idx = sb.indices()
+        assert np.array_equal(idx["neighbor_index"][0].cpu().numpy(), z["nei"][t])
+        assert np.array_equal(idx["in_flags"][0].cpu().numpy(), z["in_flags"][t])
+        assert np.array_equal(idx["sensed_index"][0].cpu().numpy(), z["sensed"][t])
+        assert np.array_equal(idx["occupied_index"][0].cpu().numpy(), z["occupied"][t])
+        assert np.array_equal(rew[0].cpu().numpy().astype(np.float64), z["rew"][t][0])
+        assert not done.any().item()
+        ref_obs = _to_rows(z["obs"][t]); ref_pri = _to_rows(z["a_prior"][t])
+        if dtype == "f32":
+            ref_obs = ref_obs.astype(np.float32); ref_pri = ref_pri.astype(np.float32)
+        assert np.array_equal(obs[0].cpu().numpy(), ref_obs)
+        assert np.array_equal(pri[0].cpu().numpy(), ref_pri)
+    sb.close()
+
+
+def test_known_answer_case():
+    """SURVEY.md section 8c hand-checkable case (topo=2, G=4, OCC=5) through the HIP path."""
+    z = load_golden(os.path.join(GOLDEN_DIR, "g1_kat_n3.npz"))
+    sb = _batch(n_env=1, n_agents=3, n_cells_max=4, r_avoid=0.15, d_sen=0.4, topo=2, g_max=4, occ_max=5,
+                obs_dtype=torch.float64)
+    sb.set_cells(z["grid"][None], [4], [0.06])
+    sb.set_state(z["p"][None], z["dp"][None])
+    obs = sb.observe()
+    idx = sb.indices()
+    assert idx["neighbor_index"][0].cpu().tolist() == [[1, -1], [0, -1], [-1, -1]]
+    assert idx["in_flags"][0].cpu().tolist() == [1, 0, 0]
+    assert idx["sensed_index"][0].cpu().tolist() == [[2, -1, -1, -1], [0, 1, 2, -1], [-1, -1, -1, -1]]
+    assert idx["occupied_index"][0].cpu().tolist() == [[0, 1, -1, -1, -1], [-1] * 5, [-1] * 5]
+    assert np.array_equal(obs[0].cpu().numpy(), _to_rows(z["obs"]))
+    sb.close()
+
+
+CONFIGS = [  # (n_a, n_env, cluster, periodic, with_self, steps)
+    (3, 5, 1, False, True, 4), (8, 16, 1, False, True, 6), (8, 9, 0, True, True, 4), (30, 6, 1, False, True, 6),
+    (32, 8, 1, False, False, 6), (32, 5, 0, False, True, 4), (64, 6, 1, False, True, 8), (64, 4, 0, False, True, 4),
+    (64, 3, 1, True, True, 4), (100, 3, 1, False, True, 3), (128, 2, 1, False, True, 3), (256, 2, 1, False, True, 3),
+    (200, 2, 0, True, False, 2),
+]
+
+
+@pytest.mark.parametrize("n_a,n_env,cluster,periodic,with_self,steps", CONFIGS)
+def test_batched_trajectories_vs_oracle(oracle, shapes, n_a, n_env, cluster, periodic, with_self, steps):
+    """E independent envs with different shapes / rotations, free-running for several steps: the state
+    trajectory, all masks and fp64 outputs stay bit-identical to E sequential oracle envs."""
+    from marl_llm_amd.shapes import r_avoid_for
+    rng = np.random.default_rng(7000 + 13 * n_a + n_env)
+    ra = r_avoid_for(n_a, shapes)
+    cases = [make_case(rng, shapes, n_a, cluster) for _ in range(n_env)]
+    ng_max = max(c[2].shape[1] for c in cases) + 3
+    cells, n_g = _pad_cells([c[2] for c in cases], ng_max)
+    sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=ng_max, r_avoid=ra, is_boundary=not periodic,
+                with_self=with_self, obs_dtype=torch.float64)
+    sb.set_cells(cells, n_g, [c[3] for c in cases])
+    p = np.stack([c[0] for c in cases]); dp = np.stack([c[1] for c in cases])
+    sb.set_state(p, dp)
+    obs0 = sb.observe().cpu().numpy()
+    idx = sb.indices()
+    nei = []
+    for e, (pe, dpe, g, l_cell) in enumerate(cases):
+        o = oracle.get_observation(pe, dpe, g, l_cell, ra, is_periodic=periodic, with_self=with_self)
+        assert np.array_equal(obs0[e], _to_rows(o["obs"])), e
+        for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+            assert np.array_equal(idx[k][e].cpu().numpy(), o[k]), (e, k)
+        nei.append(o["neighbor_index"])
+    state = [(c[0], c[1]) for c in cases]
+    for t in range(steps):
+        if t % 2 == 0:
+            act = rng.uniform(-1, 1, (n_env, n_a, 2)).astype(np.float32)
+        else:   # feed the prior back (assembles the swarm; exercises the occupied filter harder)
+            act = last_prior.astype(np.float32)
+        obs, rew, done, pri = sb.step(torch.from_numpy(act).to(sb.device))
+        obs, rew, pri = obs.cpu().numpy(), rew.cpu().numpy(), pri.cpu().numpy()
+        pg, dpg = [x.cpu().numpy() for x in sb.get_state()]
+        idx = sb.indices()
+        for e in range(n_env):
+            s = oracle.step(state[e][0], state[e][1], np.ascontiguousarray(act[e].T), cases[e][2], nei[e], cases[e][3],
+                            ra, is_boundary=not periodic, with_self=with_self)
+            assert np.array_equal(pg[e], s["p"]) and np.array_equal(dpg[e], s["dp"]), (t, e)
+            assert np.array_equal(obs[e], _to_rows(s["obs"])), (t, e)
+            assert np.array_equal(pri[e], _to_rows(s["a_prior"])), (t, e)
+            assert np.array_equal(rew[e].astype(np.float64), s["reward"][0]), (t, e)
+            for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+                assert np.array_equal(idx[k][e].cpu().numpy(), s[k]), (t, e, k)
+            state[e] = (s["p"], s["dp"]); nei[e] = s["neighbor_index"]
+        last_prior = pri
+        assert not done.any().item()
+    sb.close()
+
+
+def test_small_caps(oracle, shapes):
+    """Shrunk caps so both round(i*step) sub-samplings (80-cell and 200-cell lists) are exercised."""
+    from marl_llm_amd.shapes import r_avoid_for
+    rng = np.random.default_rng(5)
+    n_a, n_env = 32, 4
+    ra = r_avoid_for(n_a, shapes)
+    cases = [make_case(rng, shapes, n_a, 1) for _ in range(n_env)]
+    ng_max = max(c[2].shape[1] for c in cases)
+    cells, n_g = _pad_cells([c[2] for c in cases], ng_max)
+    for topo, g_max, occ_max in ((3, 10, 7), (6, 80, 20), (1, 6, 200)):
+        sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=ng_max, r_avoid=ra, topo=topo, g_max=g_max,
+                    occ_max=occ_max, obs_dtype=torch.float64)
+        sb.set_cells(cells, n_g, [c[3] for c in cases])
+        sb.set_state(np.stack([c[0] for c in cases]), np.stack([c[1] for c in cases]))
+        obs = sb.observe().cpu().numpy()
+        idx = sb.indices()
+        for e, (pe, dpe, g, l_cell) in enumerate(cases):
+            o = oracle.get_observation(pe, dpe, g, l_cell, ra, topo=topo, g_max=g_max, occ_max=occ_max)
+            assert np.array_equal(obs[e], _to_rows(o["obs"]))
+            for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+                assert np.array_equal(idx[k][e].cpu().numpy(), o[k]), (e, k)
+        sb.close()
+
+
+def test_full_size_properties(oracle, shapes):
+    """BASELINE config 64 agents x 4096 envs: size-independent invariants over the whole batch plus an
+    exact oracle comparison on a sample of environments, in the product dtype (float32 obs)."""
+    from marl_llm_amd.shapes import r_avoid_for
+    from marl_llm_amd.synth import synthetic_batch
+    n_a, n_env = 64, 4096
+    ra = r_avoid_for(n_a, shapes)
+    sy = synthetic_batch(n_env, n_a, shapes, seed=226, assembled_fraction=0.5)
+    sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra)
+    sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"])
+    sb.set_state(sy["p"], sy["dp"])
+    sb.observe()
+    nei0 = sb.indices(False, False)["neighbor_index"].cpu().numpy()
+    rng = np.random.default_rng(1)
+    act = rng.uniform(-1, 1, (n_env, n_a, 2)).astype(np.float32)
+    obs, rew, done, pri = sb.step(torch.from_numpy(act).to(sb.device))
+    obs_c, rew_c, pri_c = obs.cpu().numpy(), rew.cpu().numpy(), pri.cpu().numpy()
+    pg, dpg = [x.cpu().numpy() for x in sb.get_state()]
+    assert np.isfinite(obs_c).all() and np.isfinite(pg).all()
+    assert not done.any().item()
+    assert set(np.unique(rew_c)).issubset({0.0, 1.0})
+    assert np.abs(dpg).max() <= 0.8 and np.abs(pri_c).max() <= 1.0
+    assert (obs_c[:, :, 0] == pg[:, 0, :].astype(np.float32)).all()          # self block = absolute state
+    idx = sb.indices()
+    sen = idx["sensed_index"].cpu().numpy()
+    pad = sen < 0                                                            # unused slots are zero in obs
+    sl = obs_c[:, :, 32:].reshape(n_env, n_a, 80, 2)
+    assert (sl[pad] == 0).all()
+    assert ((sen[:, :, 1:] < 0) | (sen[:, :, :-1] >= 0)).all()               # valid slots form a prefix
+    assert (np.diff(np.where(sen >= 0, sen, 1 << 20), axis=-1) > 0)[(sen[:, :, 1:] >= 0)].all()   # ascending cell index
+    for e in rng.choice(n_env, 24, replace=False):
+        g = sy["cells"][e][:, : sy["n_g"][e]]
+        s = oracle.step(sy["p"][e], sy["dp"][e], np.ascontiguousarray(act[e].T), g, nei0[e], float(sy["l_cell"][e]), ra)
+        assert np.array_equal(pg[e], s["p"]) and np.array_equal(dpg[e], s["dp"])
+        assert np.array_equal(obs_c[e], _to_rows(s["obs"]).astype(np.float32))
+        assert np.array_equal(pri_c[e], _to_rows(s["a_prior"]).astype(np.float32))
+        assert np.array_equal(rew_c[e].astype(np.float64), s["reward"][0])
+        for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+            assert np.array_equal(idx[k][e].cpu().numpy(), s[k]), (e, k)
+    sb.close()
+
+
+def test_error_behaviour(shapes):
+    from marl_llm_amd.batched import SwarmBatch
+    from marl_llm_amd._lib import SwarmError
+    with pytest.raises(SwarmError):
+        SwarmBatch(n_env=1, n_agents=300, n_cells_max=10, r_avoid=0.1)
+    sb = SwarmBatch(n_env=2, n_agents=8, n_cells_max=600, r_avoid=0.5)
+    with pytest.raises(SwarmError):                  # step before cells/state/observe
+        sb.step(torch.zeros((2, 8, 2), device=sb.device))
+    with pytest.raises(SwarmError):
+        sb.observe()
+    with pytest.raises(SwarmError):                  # wrong action shape
+        sb.step(torch.zeros((2, 7, 2), device=sb.device))
+    sb.close()
