@@ -9,7 +9,7 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = os.path.join(PKG, "csrc", "swarm_env.hip")
+SRCS = [os.path.join(PKG, "csrc", "swarm_env.hip"), os.path.join(PKG, "csrc", "legacy_shim.hip")]
 INC = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libswarmenv.so")
@@ -25,7 +25,7 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(LIB):
         return True
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(INC, "swarm_env.h")))
+    newest = max([os.path.getmtime(s) for s in SRCS] + [os.path.getmtime(os.path.join(INC, "swarm_env.h"))])
     return os.path.getmtime(LIB) < newest
 
 
@@ -34,7 +34,7 @@ def build_lib(force=False, verbose=False):
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I" + INC, SRC, "-o", LIB]
+           "-I" + INC] + SRCS + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
