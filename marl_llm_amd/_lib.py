@@ -37,10 +37,11 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB):
-        raise SwarmError(f"{LIB} not found: build it with `python -m marl_llm_amd.build` "
+    path = os.environ.get("SWARM_LIB", LIB)      # SWARM_LIB: diagnostic builds only (tools/)
+    if not os.path.exists(path):
+        raise SwarmError(f"{path} not found: build it with `python -m marl_llm_amd.build` "
                          "(there is no CPU fallback for the env step)")
-    lib = ctypes.CDLL(LIB)
+    lib = ctypes.CDLL(path)
     vp, i32, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     lib.swarm_abi_version.restype = i32
     lib.swarm_default_config.argtypes = [ctypes.POINTER(SwarmConfig)]; lib.swarm_default_config.restype = None

@@ -29,16 +29,19 @@ def needs_build():
     return os.path.getmtime(LIB) < newest
 
 
-def build_lib(force=False, verbose=False):
-    if not force and not needs_build():
+def build_lib(force=False, verbose=False, stamps=False):
+    """stamps=True builds the DIAGNOSTIC library libswarmenv_stamps.so (per-phase in-kernel clocks, used by
+    tools/phase_profile.py); its timings are never quoted as product numbers."""
+    out = LIB if not stamps else os.path.join(LIB_DIR, "libswarmenv_stamps.so")
+    if not stamps and not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I" + INC] + SRCS + ["-o", LIB]
+           "-I" + INC] + (["-DSWARM_STAMPS"] if stamps else []) + SRCS + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -46,7 +46,8 @@ struct KP {
     int with_self, periodic, boundary, with_prior, export_idx;
     int cxy_stride;            // double2 elements per env in LDS
     int g_stride;              // int16 elements per agent row in LDS
-    int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, smem_bytes;
+    int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear, off_pc;
+    int smem_bytes, smem_bytes_export;
     double c_sen, c_near, c_occ, c_avoid, c_ball;     // squared-distance cut-offs
     double d_sen, r_avoid, size_a, size2, k_ball, k_wall, c_wall, vel_max, dt;
     double bx0, by1, bx2, by3, w_half, h_half;
@@ -56,6 +57,7 @@ struct KP {
     const int *n_g;
     const double *c_in;
     int *exp_sensed, *exp_occ;
+    long long *stamps;         // diagnostic build only (-DSWARM_STAMPS): per-block phase clocks
 };
 
 template <typename T> struct Pair;
@@ -74,29 +76,85 @@ __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
     return (lo < m) ? m : lo;
 }
 
+#ifdef SWARM_STAMPS
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); stamp_t[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// Workgroup geometry.  AG "agent threads" hold the agents of the workgroup's environment(s) (lane = agent);
+// the workgroup has WPE copies ("splits") of them.  Split 0 owns the per-agent sequential work (forces,
+// integration, neighbour search); the target-cell words of the scan / filter / list phases are dealt out
+// over all splits, split 0 getting fewer.  One environment's LDS footprint is thereby shared by WPE times
+// more wavefronts, which is what buys the occupancy that hides the LDS / fp64 latencies.
+template <int NPAD> struct Geo {
+    static constexpr int AG = NPAD < 64 ? 64 : NPAD;
+    static constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
+    static constexpr int NW = AG / 64;
+    static constexpr int WPE = NPAD <= 64 ? 4 : 2;
+    static constexpr int T = AG * WPE;
+};
+
+constexpr double kSentinel = 1.0e200;     // coordinates of padding cells: d2 overflows to +inf
+
+// cos(pi * t) for t in [0, 1], absolute error ~2e-16 (Taylor in x = pi*min(t, 1-t) <= pi/2 up to x^22).
+// Only the reward's psi weights use it (CPP:1012-1020 calls libm cos(M_PI * z / r)); it is not bit-identical
+// to glibc's cos and does not need to be: it feeds a sum that is compared with a threshold.
+__device__ __forceinline__ double cospi01(double t)
+{
+    const bool flip = t > 0.5;
+    const double r = flip ? 1.0 - t : t;
+    const double x = M_PI * r;
+    const double u = x * x;
+    double c = -8.8967913924505741e-22;                 // -1/22!
+    c = fma(c, u, 4.1103176233121648e-19);              // +1/20!
+    c = fma(c, u, -1.5619206968586225e-16);
+    c = fma(c, u, 4.7794773323873853e-14);
+    c = fma(c, u, -1.1470745597729725e-11);
+    c = fma(c, u, 2.0876756987868100e-09);
+    c = fma(c, u, -2.7557319223985888e-07);
+    c = fma(c, u, 2.4801587301587302e-05);
+    c = fma(c, u, -1.3888888888888889e-03);
+    c = fma(c, u, 4.1666666666666664e-02);
+    c = fma(c, u, -0.5);
+    c = fma(c, u, 1.0);
+    return flip ? -c : c;
+}
+
 template <int NPAD, typename OT, bool DO_STEP>
-__global__ void __launch_bounds__((NPAD < 64 ? 64 : NPAD))
+__global__ void __launch_bounds__(Geo<NPAD>::T)
 k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__restrict__ obs,
       float *__restrict__ reward, uint8_t *__restrict__ done, OT *__restrict__ a_prior)
 {
-    constexpr int T = NPAD < 64 ? 64 : NPAD;
-    constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
-    constexpr int NW = T / 64;
+    constexpr int AG = Geo<NPAD>::AG, EPB = Geo<NPAD>::EPB, NW = Geo<NPAD>::NW, WPE = Geo<NPAD>::WPE, T = Geo<NPAD>::T;
     typedef typename Pair<OT>::type OT2;
 
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *cxy = reinterpret_cast<double2 *>(smem + P.off_cxy);
-    double *sp = reinterpret_cast<double *>(smem + P.off_sp);          // [4][T]: px, py, vx, vy
-    u64 *cmask = reinterpret_cast<u64 *>(smem + P.off_cmask);          // [cell][NW]
-    unsigned *sbits = reinterpret_cast<unsigned *>(smem + P.off_sbits); // [word][T]
-    unsigned *obits = reinterpret_cast<unsigned *>(smem + P.off_obits); // [word][T] (export only)
-    short *sidx = reinterpret_cast<short *>(smem + P.off_sidx);        // [T][g_stride]
-    short *snei = reinterpret_cast<short *>(smem + P.off_snei);        // [T][kTopoMax]
-    int *sncf = reinterpret_cast<int *>(smem + P.off_sncf);            // [T]: nearest cell | in_flag<<30
+    double *sp = reinterpret_cast<double *>(smem + P.off_sp);            // [4][AG]: px, py, vx, vy
+    u64 *cmask = reinterpret_cast<u64 *>(smem + P.off_cmask);            // [cell][NW]
+    double *rsum = reinterpret_cast<double *>(smem + P.off_cmask);       // [WPE][3][AG]  (aliases cmask, later phase)
+    unsigned *sbits = reinterpret_cast<unsigned *>(smem + P.off_sbits);  // [word][AG]
+    unsigned *obits = reinterpret_cast<unsigned *>(smem + P.off_obits);  // [word][AG] (export launches only)
+    short *sidx = reinterpret_cast<short *>(smem + P.off_sidx);          // [AG][g_stride]
+    double *part_d = reinterpret_cast<double *>(smem + P.off_sidx);      // [WPE][AG]     (aliases sidx, earlier phase)
+    int *part_c = reinterpret_cast<int *>(smem + P.off_sidx + (size_t)WPE * AG * 8);   // [WPE][AG]
+    short *snei = reinterpret_cast<short *>(smem + P.off_snei);          // [AG][kTopoMax]
+    int *sncf = reinterpret_cast<int *>(smem + P.off_sncf);              // [AG]: nearest cell | in_flag<<30
+    u64 *snear = reinterpret_cast<u64 *>(smem + P.off_snear);            // [NW][AG] nearby-agent masks
+    unsigned char *pc = smem + P.off_pc;                                 // [word][AG] kept-bit counts
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int el = NPAD < 64 ? tid / NPAD : 0;
-    const int i = NPAD < 64 ? tid % NPAD : tid;
+#ifdef SWARM_STAMPS
+    long long stamp_t[10];
+    for (int k = 0; k < 10; ++k) stamp_t[k] = 0;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    STAMP(0);
+    const int at = tid % AG;                 // agent thread
+    const int sx = tid / AG;                 // split (wave-uniform)
+    const int aw = at >> 6;                  // which 64-agent group of the environment
+    const int el = NPAD < 64 ? at / NPAD : 0;
+    const int i = NPAD < 64 ? at % NPAD : at;
     const int e = blockIdx.x * EPB + el;
     const int n_a = P.n_a;
     const bool act = (e < P.n_env) && (i < n_a);
@@ -105,261 +163,361 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     int ngb = ng;
     if (EPB > 1) {
         for (int k = 0; k < EPB; ++k) {
-            int ek = blockIdx.x * EPB + k;
-            int v = P.n_g[ek < P.n_env ? ek : P.n_env - 1];
+            const int ek = blockIdx.x * EPB + k;
+            const int v = P.n_g[ek < P.n_env ? ek : P.n_env - 1];
             ngb = v > ngb ? v : ngb;
         }
     }
-    const int ngwb = (ngb + 31) >> 5;
+    const int W = (ngb + 31) >> 5;                       // target-cell words of this workgroup
+    // words [0, w0) belong to split 0, the rest are dealt round-robin to splits 1..WPE-1
+    int w0 = W;
+    if (WPE > 1) { w0 = (W - (DO_STEP ? 3 : 2) * (WPE - 1)) / WPE; w0 = w0 < 0 ? 0 : w0; }
+    auto mine = [&](int w) -> bool {
+        if (WPE == 1) return true;
+        return w < w0 ? (sx == 0) : (sx == 1 + (w - w0) % (WPE - 1));
+    };
     double2 *cxy_e = cxy + (size_t)el * P.cxy_stride;
 
-    // ---- stage this env's target cells (ENV: grid_center (2, n_g)) in LDS as (x, y) pairs
-    {
-        const double *gx = P.cells + (size_t)es * 2 * P.ng_max;
+    // ---- stage the target cells (ENV: grid_center (2, n_g)) in LDS as (x, y) pairs; pad with a sentinel
+    for (int k = 0; k < EPB; ++k) {
+        const int ek0 = blockIdx.x * EPB + k;
+        const int ek = ek0 < P.n_env ? ek0 : P.n_env - 1;
+        const int ngk = P.n_g[ek];
+        const double *gx = P.cells + (size_t)ek * 2 * P.ng_max;
         const double *gy = gx + P.ng_max;
-        for (int c = i; c < ngwb * 32; c += NPAD) {
+        for (int c = tid; c < W * 32; c += T) {
             double2 g;
-            g.x = c < ng ? gx[c] : 0.0;
-            g.y = c < ng ? gy[c] : 0.0;
-            cxy_e[c] = g;
+            g.x = c < ngk ? gx[c] : kSentinel;
+            g.y = c < ngk ? gy[c] : kSentinel;
+            cxy[(size_t)k * P.cxy_stride + c] = g;
         }
     }
-    // ---- state
-    double px = 0, py = 0, vx = 0, vy = 0;
+    // ---- state (inactive lanes carry NaN positions: every comparison with them is false)
     const size_t sbase = (size_t)es * 2 * n_a;
-    if (act) {
-        px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
-        vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
+    double px = __builtin_nan(""), py = __builtin_nan(""), vx = 0.0, vy = 0.0;
+    if (sx == 0) {
+        if (act) {
+            px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
+            vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
+        }
+        sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy;
     }
-    sp[tid] = px; sp[T + tid] = py; sp[2 * T + tid] = vx; sp[3 * T + tid] = vy;
     __syncthreads();
+    STAMP(1);
 
     if (DO_STEP) {
-        // ---- ball-to-ball contact spring: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all).
-        // Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped when
-        // periodic), d_center unwrapped for every pair the reference evaluates (its numpy wrap only touches
-        // agent 0's row, which the i>j loop never reads).  Summed over k in index order.
-        double sfx = 0.0, sfy = 0.0;
-        for (int k = 0; k < n_a; ++k) {
-            const int tk = el * NPAD + k;
-            const double dx = sp[tk] - px, dy = sp[T + tk] - py;
-            const double d2 = dx * dx + dy * dy;
-            if (act && k != i && d2 < P.c_ball) {
-                const double dc = sqrt(d2);
-                const double de = fabs(dc - P.size2);
-                double wx = dx, wy = dy;
-                if (P.periodic) wrap_rel(wx, wy, P.w_half, P.h_half);
-                const double ux = wx / dc, uy = wy / dc;
-                sfx += 1.0 * de * P.k_ball * (-ux);
-                sfy += 1.0 * de * P.k_ball * (-uy);
-            }
-        }
-        double ax = 0.0, ay = 0.0;
-        if (act) {
-            const size_t ab = ((size_t)e * n_a + i) * 2;
-            if (act_f64) { ax = ((const double *)action)[ab]; ay = ((const double *)action)[ab + 1]; }
-            else { ax = (double)((const float *)action)[ab]; ay = (double)((const float *)action)[ab + 1]; }
-        }
-        double Fx = 1 * ax + sfx, Fy = 1 * ay + sfy;                       // ENV:638,640
-        if (P.boundary) {                                                   // CPP:817-855, ENV:515-518
-            const double d0 = px - P.size_a - P.bx0;
-            const double d1 = P.by1 - (py + P.size_a);
-            const double d2 = P.bx2 - (px + P.size_a);
-            const double d3 = py - P.size_a - P.by3;
-            const double a0 = d0 < 0 ? fabs(d0) : 0.0, a1 = d1 < 0 ? fabs(d1) : 0.0;
-            const double a2 = d2 < 0 ? fabs(d2) : 0.0, a3 = d3 < 0 ? fabs(d3) : 0.0;
-            const double sx = (a0 - a2) * P.k_wall, sy = (a3 - a1) * P.k_wall;
-            const double v0 = d0 < 0 ? vx : 0.0, v2 = d2 < 0 ? vx : 0.0;
-            const double v3 = d3 < 0 ? vy : 0.0, v1 = d1 < 0 ? vy : 0.0;
-            const double gx = (-v0 - v2) * P.c_wall, gy = (-v3 - v1) * P.c_wall;
-            Fx = Fx + sx + gx;
-            Fy = Fy + sy + gy;
-        }
-        // ---- prior policy on the PRE-integration state with the previous neighbour list:
-        // CPP:1061-1196 via ENV:605-624.  The nearest cell / in-shape flag of the pre-integration
-        // position are the ones the previous observation pass cached.
-        if (P.with_prior && act && a_prior != nullptr) {
-            const int ncell = P.near_cell[(size_t)e * n_a + i];
-            const int inf = P.in_flag[(size_t)e * n_a + i];
-            double tx, ty;
-            if (inf) { tx = px - px; ty = py - py; }
-            else { const double2 g = cxy_e[ncell]; tx = g.x - px; ty = g.y - py; }
-            double qx = 0.0, qy = 0.0;
-            const double dt_ = sqrt(tx * tx + ty * ty);
-            if (dt_ > 0) { qx += 2.0 * tx / dt_; qy += 2.0 * ty / dt_; }
-            double avx = 0.0, avy = 0.0; int cnt = 0;
-            for (int k = 0; k < P.topo; ++k) {
-                const int j = P.nei[((size_t)e * n_a + i) * P.topo + k];
-                if (j < 0) continue;
-                const int tj = el * NPAD + j;
-                const double x = px - sp[tj], y = py - sp[T + tj];
-                const double d = sqrt(x * x + y * y);
-                if (d > 0 && d < P.r_avoid) {
-                    const double ux = x / d, uy = y / d;
-                    const double factor = 3.0 * (P.r_avoid / d - 1.0);
-                    qx += factor * ux; qy += factor * uy;
+        double npx = px, npy = py, nvx = vx, nvy = vy;
+        if (sx == 0) {
+            // ---- ball-to-ball contact spring: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all).
+            // Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped when
+            // periodic), d_center un-wrapped for every pair the reference evaluates (its numpy wrap only touches
+            // agent 0's row, which the i>j loop never reads).  Summed over k in index order.
+            // issue every global load of this phase up front so their latency overlaps the contact loop
+            int pj[kTopoMax]; int ncell = 0, inf = 0;
+            double ax = 0.0, ay = 0.0;
+#pragma unroll
+            for (int k = 0; k < kTopoMax; ++k) pj[k] = -1;
+            if (act) {
+                const size_t ab = ((size_t)e * n_a + i) * 2;
+                if (act_f64) { ax = ((const double *)action)[ab]; ay = ((const double *)action)[ab + 1]; }
+                else { const float2 af = reinterpret_cast<const float2 *>(action)[(size_t)e * n_a + i]; ax = (double)af.x; ay = (double)af.y; }
+                if (P.with_prior) {
+                    ncell = P.near_cell[(size_t)e * n_a + i];
+                    inf = P.in_flag[(size_t)e * n_a + i];
+#pragma unroll
+                    for (int k = 0; k < kTopoMax; ++k)
+                        if (k < P.topo) pj[k] = P.nei[((size_t)e * n_a + i) * P.topo + k];
                 }
-                avx += sp[2 * T + tj]; avy += sp[3 * T + tj]; ++cnt;
             }
-            if (cnt > 0) {
-                avx /= cnt; avy /= cnt;
-                qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
+            double sfx = 0.0, sfy = 0.0;
+            {
+                constexpr int KN = NPAD < 64 ? NPAD : 64;       // lanes >= n_a hold NaN positions: never "colliding"
+                const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
+                for (int kb = 0; kb < NW * 64 && kb < NPAD; kb += KN) {
+#pragma unroll 8
+                    for (int kk = 0; kk < KN; ++kk) {
+                        const int k = kb + kk;
+                        const double dx = spx[k] - px, dy = spy[k] - py;
+                        const double d2 = dx * dx + dy * dy;
+                        if (k != i && d2 < P.c_ball) {
+                            const double dc = sqrt(d2);
+                            const double de = fabs(dc - P.size2);
+                            double wx = dx, wy = dy;
+                            if (P.periodic) wrap_rel(wx, wy, P.w_half, P.h_half);
+                            const double ux = wx / dc, uy = wy / dc;
+                            sfx += 1.0 * de * P.k_ball * (-ux);
+                            sfy += 1.0 * de * P.k_ball * (-uy);
+                        }
+                    }
+                }
             }
-            OT2 o; o.x = (OT)clamp_ref(qx, -1.0, 1.0); o.y = (OT)clamp_ref(qy, -1.0, 1.0);
-            reinterpret_cast<OT2 *>(a_prior)[(size_t)e * n_a + i] = o;
-        }
-        // ---- integration, ENV:643-652
-        double nvx = vx + (Fx / 1.0) * P.dt, nvy = vy + (Fy / 1.0) * P.dt;
-        nvx = nvx < -P.vel_max ? -P.vel_max : (nvx > P.vel_max ? P.vel_max : nvx);
-        nvy = nvy < -P.vel_max ? -P.vel_max : (nvy > P.vel_max ? P.vel_max : nvy);
-        double npx = px + nvx * P.dt, npy = py + nvy * P.dt;
-        if (P.periodic) {                                                    // ENV:773-776
-            if (npx < P.bx0) npx += 2 * P.w_half;
-            if (npx > P.bx2) npx -= 2 * P.w_half;
-            if (npy < P.by3) npy += 2 * P.h_half;
-            if (npy > P.by1) npy -= 2 * P.h_half;
+            double Fx = 1 * ax + sfx, Fy = 1 * ay + sfy;                       // ENV:638,640
+            if (P.boundary) {                                                   // CPP:817-855, ENV:515-518
+                const double d0 = px - P.size_a - P.bx0;
+                const double d1 = P.by1 - (py + P.size_a);
+                const double d2 = P.bx2 - (px + P.size_a);
+                const double d3 = py - P.size_a - P.by3;
+                const double a0 = d0 < 0 ? fabs(d0) : 0.0, a1 = d1 < 0 ? fabs(d1) : 0.0;
+                const double a2 = d2 < 0 ? fabs(d2) : 0.0, a3 = d3 < 0 ? fabs(d3) : 0.0;
+                const double sx_ = (a0 - a2) * P.k_wall, sy_ = (a3 - a1) * P.k_wall;
+                const double v0 = d0 < 0 ? vx : 0.0, v2 = d2 < 0 ? vx : 0.0;
+                const double v3 = d3 < 0 ? vy : 0.0, v1 = d1 < 0 ? vy : 0.0;
+                const double gx = (-v0 - v2) * P.c_wall, gy = (-v3 - v1) * P.c_wall;
+                Fx = Fx + sx_ + gx;
+                Fy = Fy + sy_ + gy;
+            }
+            // ---- prior policy on the PRE-integration state with the previous neighbour list:
+            // CPP:1061-1196 via ENV:605-624.  The nearest cell / in-shape flag of the pre-integration
+            // position are the ones the previous observation pass cached.
+            if (P.with_prior && act && a_prior != nullptr) {
+                double tx, ty;
+                if (inf) { tx = px - px; ty = py - py; }
+                else { const double2 g = cxy_e[ncell]; tx = g.x - px; ty = g.y - py; }
+                double qx = 0.0, qy = 0.0;
+                const double dt_ = sqrt(tx * tx + ty * ty);
+                if (dt_ > 0) { qx += 2.0 * tx / dt_; qy += 2.0 * ty / dt_; }
+                double avx = 0.0, avy = 0.0; int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < kTopoMax; ++k) {
+                    const int j = pj[k];
+                    if (j < 0) continue;
+                    const int tj = el * NPAD + j;
+                    const double x = px - sp[tj], y = py - sp[AG + tj];
+                    const double d = sqrt(x * x + y * y);
+                    if (d > 0 && d < P.r_avoid) {
+                        const double ux = x / d, uy = y / d;
+                        const double factor = 3.0 * (P.r_avoid / d - 1.0);
+                        qx += factor * ux; qy += factor * uy;
+                    }
+                    avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt;
+                }
+                if (cnt > 0) {
+                    avx /= cnt; avy /= cnt;
+                    qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
+                }
+                OT2 o; o.x = (OT)clamp_ref(qx, -1.0, 1.0); o.y = (OT)clamp_ref(qy, -1.0, 1.0);
+                reinterpret_cast<OT2 *>(a_prior)[(size_t)e * n_a + i] = o;
+            }
+            // ---- integration, ENV:643-652
+            nvx = vx + (Fx / 1.0) * P.dt; nvy = vy + (Fy / 1.0) * P.dt;
+            nvx = nvx < -P.vel_max ? -P.vel_max : (nvx > P.vel_max ? P.vel_max : nvx);
+            nvy = nvy < -P.vel_max ? -P.vel_max : (nvy > P.vel_max ? P.vel_max : nvy);
+            npx = px + nvx * P.dt; npy = py + nvy * P.dt;
+            if (P.periodic) {                                                    // ENV:773-776
+                if (npx < P.bx0) npx += 2 * P.w_half;
+                if (npx > P.bx2) npx -= 2 * P.w_half;
+                if (npy < P.by3) npy += 2 * P.h_half;
+                if (npy > P.by1) npy -= 2 * P.h_half;
+            }
         }
         __syncthreads();                 // every lane is done with the old positions in LDS
-        px = npx; py = npy; vx = nvx; vy = nvy;
-        sp[tid] = px; sp[T + tid] = py; sp[2 * T + tid] = vx; sp[3 * T + tid] = vy;
-        if (act) {
-            P.p[sbase + i] = px; P.p[sbase + n_a + i] = py;
-            P.dp[sbase + i] = vx; P.dp[sbase + n_a + i] = vy;
+        if (sx == 0) {
+            sp[at] = npx; sp[AG + at] = npy; sp[2 * AG + at] = nvx; sp[3 * AG + at] = nvy;
+            if (act) {
+                P.p[sbase + i] = npx; P.p[sbase + n_a + i] = npy;
+                P.dp[sbase + i] = nvx; P.dp[sbase + n_a + i] = nvy;
+            }
         }
         __syncthreads();
     }
+    px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at];
+    STAMP(2);
 
-    // ---- neighbour search, CPP:77-100 + _get_focused CPP:628-698: the topo nearest agents with
+    // ---- neighbour search (split 0), CPP:77-100 + _get_focused CPP:628-698: the topo nearest agents with
     // norm < d_sen (self removed), ascending.  Also the "nearby" agent mask of the occupied-cell filter
     // (CPP:152-164: un-wrapped distance < d_sen + r_avoid/2, self included).
-    double nd[kTopoMax]; int nj[kTopoMax];
+    bool collision = false;
+    if (sx == 0) {
+        double nd[kTopoMax]; int nj[kTopoMax];
 #pragma unroll
-    for (int k = 0; k < kTopoMax; ++k) { nd[k] = INFINITY; nj[k] = -1; }
-    u64 nearby[NW];
+        for (int k = 0; k < kTopoMax; ++k) { nd[k] = INFINITY; nj[k] = -1; }
+        u64 nearby[NW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) nearby[w] = 0;
+        for (int w = 0; w < NW; ++w) nearby[w] = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const int jn = NPAD < 64 ? NPAD : 64;
-        for (int jj = 0; jj < jn; ++jj) {
-            const int j = w * 64 + jj;
-            if (j >= n_a) break;
-            const int tj = el * NPAD + j;
-            double rx = sp[tj] - px, ry = sp[T + tj] - py;
-            const double d2u = rx * rx + ry * ry;
-            if (act && d2u < P.c_near) nearby[w] |= 1ull << (tj & 63);
-            double d2 = d2u;
-            if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-            if (act && j != i && d2 < P.c_sen) {
-                double cd = d2; int cj = j;
+        for (int w = 0; w < NW; ++w) {
+            constexpr int JN = NPAD < 64 ? NPAD : 64;           // lanes >= n_a hold NaN positions: never candidates
+            constexpr int JB = 8;
+            const double *spx = sp + el * NPAD + w * 64, *spy = sp + AG + el * NPAD + w * 64;
+            for (int jb = 0; jb < JN; jb += JB) {
+                double d2b[JB];
+                u64 nb = 0;
 #pragma unroll
-                for (int k = 0; k < kTopoMax; ++k) {
-                    const bool s = cd < nd[k];
-                    const double td = nd[k]; const int tjj = nj[k];
-                    nd[k] = s ? cd : td; nj[k] = s ? cj : tjj;
-                    cd = s ? td : cd;    cj = s ? tjj : cj;
+                for (int q = 0; q < JB; ++q) {                  // stage 1: JB independent distance evaluations
+                    double rx = spx[jb + q] - px, ry = spy[jb + q] - py;
+                    const double d2u = rx * rx + ry * ry;
+                    if (d2u < P.c_near) nb |= 1ull << ((el * NPAD + jb + q) & 63);
+                    double d2 = d2u;
+                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
+                    d2b[q] = (w * 64 + jb + q != i && d2 < P.c_sen) ? d2 : INFINITY;
+                }
+                nearby[w] |= nb;
+#pragma unroll
+                for (int q = 0; q < JB; ++q) {                  // stage 2: ordered insertion of the candidates
+                    if (d2b[q] < INFINITY) {
+                        double cd = d2b[q]; int cj = w * 64 + jb + q;
+#pragma unroll
+                        for (int k = 0; k < kTopoMax; ++k) {
+                            const bool s = cd < nd[k];
+                            const double td = nd[k]; const int tjj = nj[k];
+                            nd[k] = s ? cd : td; nj[k] = s ? cj : tjj;
+                            cd = s ? td : cd;    cj = s ? tjj : cj;
+                        }
+                    }
                 }
             }
         }
-    }
-    bool collision = false;                                   // CPP:459-491 (on the NEW neighbour list)
 #pragma unroll
-    for (int k = 0; k < kTopoMax; ++k) {
-        const bool used = k < P.topo && nj[k] >= 0;
-        snei[tid * kTopoMax + k] = (short)(used ? nj[k] : -1);
-        if (used && nd[k] < P.c_avoid) collision = true;
-        if (act && k < P.topo) P.nei[((size_t)e * n_a + i) * P.topo + k] = used ? nj[k] : -1;
-    }
-
-    // ---- target-cell scan, _get_target_grid_state CPP:858-908: first-minimum nearest cell, sensed-cell
-    // bits (d < d_sen), and per cell the ballot of agents with d <= r_avoid/2 (CPP:183-186 inverted).
-    double best = INFINITY; int bc = 0;
-    {
-        u64 mym = 0;
-        for (int w = 0; w < ngwb; ++w) {
-            unsigned word = 0;
-            for (int b = 0; b < 32; ++b) {
-                const int c = w * 32 + b;
-                const double2 g = cxy_e[c];
-                const double rx = g.x - px, ry = g.y - py;
-                const double d2 = rx * rx + ry * ry;
-                const bool valid = act && c < ng;
-                if (valid && d2 < best) { best = d2; bc = c; }
-                if (valid && d2 < P.c_sen) word |= 1u << b;
-                const u64 m = __ballot(valid && d2 < P.c_occ);
-                if (lane == (c & 63)) mym = m;
-            }
-            sbits[w * T + tid] = word;
-            if ((w & 1) || w == ngwb - 1) cmask[(size_t)((w >> 1) * 64 + lane) * NW + wave] = mym;
+        for (int w = 0; w < NW; ++w) snear[w * AG + at] = nearby[w];
+#pragma unroll
+        for (int k = 0; k < kTopoMax; ++k) {                      // CPP:459-491 collision test on the NEW list
+            const bool used = k < P.topo && nj[k] >= 0;
+            snei[at * kTopoMax + k] = (short)(used ? nj[k] : -1);
+            if (used && nd[k] < P.c_avoid) collision = true;
+            if (act && k < P.topo) P.nei[((size_t)e * n_a + i) * P.topo + k] = used ? nj[k] : -1;
         }
     }
-    const bool in_shape = act && ng > 0 && best < P.c_in[es];          // CPP:889
-    sncf[tid] = bc | (in_shape ? (1 << 30) : 0);
-    if (act) {
-        P.near_cell[(size_t)e * n_a + i] = bc;
-        P.in_flag[(size_t)e * n_a + i] = in_shape ? 1 : 0;
+    STAMP(3);
+
+    // ---- target-cell scan over this split's words, _get_target_grid_state CPP:858-908: first-minimum
+    // nearest cell, sensed-cell bits (d < d_sen), and per cell the ballot of agents with d <= r_avoid/2
+    // (CPP:183-186 inverted).
+    double best = INFINITY; int bc = 0;
+    for (int w = 0; w < W; ++w) {
+        if (!mine(w)) continue;
+        unsigned word = 0;
+        u64 mym = 0;
+        const double2 *cw = cxy_e + w * 32;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) {
+            const double2 g = cw[b];
+            const double rx = g.x - px, ry = g.y - py;
+            const double d2 = rx * rx + ry * ry;
+            if (d2 < best) { best = d2; bc = w * 32 + b; }
+            if (d2 < P.c_sen) word |= 1u << b;
+            const u64 m = __ballot(d2 < P.c_occ);
+            if (lane == b) mym = m;
+        }
+        sbits[w * AG + at] = word;
+        if (lane < 32) cmask[(size_t)(w * 32 + lane) * NW + aw] = mym;
     }
+    part_d[sx * AG + at] = best; part_c[sx * AG + at] = bc;
     __syncthreads();
+    best = INFINITY; bc = 0;
+#pragma unroll
+    for (int s = 0; s < WPE; ++s) {
+        const double d = part_d[s * AG + at]; const int c = part_c[s * AG + at];
+        if (d < best || (d == best && c < bc)) { best = d; bc = c; }
+    }
+    const bool in_shape = act && best < P.c_in[es];                    // CPP:889
+    if (sx == 0) {
+        sncf[at] = bc | (in_shape ? (1 << 30) : 0);
+        if (act) {
+            P.near_cell[(size_t)e * n_a + i] = bc;
+            P.in_flag[(size_t)e * n_a + i] = in_shape ? 1 : 0;
+        }
+    }
+    STAMP(4);
 
     // ---- occupied-cell filter, CPP:144-216: a sensed cell is occupied iff some nearby agent is within
     // r_avoid/2 of it; only agents inside the shape filter (CPP:150).
-    int n_kept = 0, n_occ = 0;
-    for (int w = 0; w < ngwb; ++w) {
-        const unsigned word = sbits[w * T + tid];
-        unsigned kw = word;
-        if (in_shape) {
-            unsigned it = word;
-            while (it) {
-                const int b = __ffs(it) - 1;
-                it &= it - 1;
-                const int c = w * 32 + b;
-                bool occ = false;
-#pragma unroll
-                for (int q = 0; q < NW; ++q) occ = occ || ((cmask[(size_t)c * NW + q] & nearby[q]) != 0);
-                if (occ) kw &= ~(1u << b);
-            }
-            sbits[w * T + tid] = kw;
-        }
-        if (P.export_idx) obits[w * T + tid] = word & ~kw;
-        n_kept += __popc(kw);
-        n_occ += __popc(word & ~kw);
-    }
-
-    // ---- capped sensed list (CPP:236-271) into LDS, and the exploration reward over it (CPP:494-551)
     {
-        const int G = P.g_max;
+        u64 nearby[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) nearby[q] = in_shape ? snear[q * AG + at] : 0;
+        for (int w = 0; w < W; ++w) {
+            if (!mine(w)) continue;
+            const unsigned word = sbits[w * AG + at];
+            unsigned kw = word;
+            if (in_shape) {
+                unsigned it = word;
+                while (it) {
+                    int bb[4]; bool occ[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { bb[u] = it ? __ffs(it) - 1 : -1; it &= it - 1; }   // it - 1 of 0 is harmless: it stays 0
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = w * 32 + (bb[u] < 0 ? 0 : bb[u]);
+                        occ[u] = false;
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) occ[u] = occ[u] || ((cmask[(size_t)c * NW + q] & nearby[q]) != 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (bb[u] >= 0 && occ[u]) kw &= ~(1u << bb[u]);
+                }
+                sbits[w * AG + at] = kw;
+            }
+            if (P.export_idx) obits[w * AG + at] = word & ~kw;
+            pc[w * AG + at] = (unsigned char)__popc(kw);
+        }
+    }
+    __syncthreads();
+    STAMP(5);
+
+    // ---- capped sensed list (CPP:236-271) into LDS, and the exploration reward's sums over it (CPP:494-551).
+    // Each split emits the slots of its own words (rank = prefix of the kept-bit counts) and accumulates
+    // partial sums; the sums are combined in split order below.
+    int n_kept = 0;
+    for (int w = 0; w < W; ++w) n_kept += pc[w * AG + at];
+    const int G = P.g_max;
+    const int n_sel = n_kept > G ? G : n_kept;
+    {
         const bool sub = n_kept > G;
         const double step = sub ? (double)(n_kept - 1) / (G - 1) : 0.0;
-        int s = 0, k = 0, target = 0;
-        double num0 = 0.0, num1 = 0.0, den = 0.0;
-        short *row = sidx + (size_t)tid * P.g_stride;
-        for (int w = 0; w < ngwb; ++w) {
-            unsigned it = sbits[w * T + tid];
-            while (it) {
-                const int b = __ffs(it) - 1;
-                it &= it - 1;
-                const int c = w * 32 + b;
-                const bool sel = sub ? (k == target) : true;
-                if (sel && s < G) {
-                    row[s] = (short)c;
-                    if (in_shape) {
-                        const double2 g = cxy_e[c];
-                        const double x = g.x - px, y = g.y - py;
-                        const double z = sqrt(x * x + y * y);
-                        double psi;                                   // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020
-                        if (z < 0.0 * P.d_sen) psi = 1.0;
-                        else if (z < P.d_sen) psi = (1.0 / 2.0) * (1.0 + cos(M_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
-                        else psi = 0.0;
-                        num0 += psi * x; num1 += psi * y; den += psi;
-                    }
-                    ++s;
-                    if (sub) target = (int)round(s * step);
+        int s = 0, target = 0, prefix = 0;
+        short *row = sidx + (size_t)at * P.g_stride;
+        for (int w = 0; w < W; ++w) {
+            const int cnt = pc[w * AG + at];
+            if (mine(w)) {
+                unsigned it = sbits[w * AG + at];
+                int k = prefix;
+                while (it) {
+                    const int b = __ffs(it) - 1;
+                    it &= it - 1;
+                    const int c = w * 32 + b;
+                    bool sel;
+                    if (sub) {
+                        while (target < k && s < G) { ++s; target = (int)round(s * step); }   // CPP:245
+                        sel = (s < G) && (target == k);
+                    } else { s = k; sel = true; }
+                    if (sel) row[s] = (short)c;
+                    ++k;
                 }
-                ++k;
+            }
+            prefix += cnt;
+        }
+        for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
+    }
+    __syncthreads();
+    // exploration-reward sums over the capped list (CPP:494-551): split sx takes slots sx, sx+WPE, ...;
+    // independent iterations (unrolled) instead of a serial bit walk.
+    {
+        const double inv_dsen = 1.0 / P.d_sen;
+        double num0 = 0.0, num1 = 0.0, den = 0.0;
+        const short *row = sidx + (size_t)at * P.g_stride;
+        const int lim = in_shape ? n_sel : 0;
+#pragma unroll 4
+        for (int q = sx; q < G; q += WPE) {
+            if (q < lim) {
+                const double2 g = cxy_e[row[q]];
+                const double x = g.x - px, y = g.y - py;
+                const double z = sqrt(x * x + y * y);
+                // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
+                const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
+                num0 += psi * x; num1 += psi * y; den += psi;
             }
         }
-        const int n_sel = s;
-        for (; s < G; ++s) row[s] = -1;
+        rsum[(sx * 3 + 0) * AG + at] = num0; rsum[(sx * 3 + 1) * AG + at] = num1; rsum[(sx * 3 + 2) * AG + at] = den;
+    }
+    __syncthreads();
+    STAMP(6);
+
+    if (sx == 0) {
+        double num0 = 0.0, num1 = 0.0, den = 0.0;
+#pragma unroll
+        for (int s = 0; s < WPE; ++s) {
+            num0 += rsum[(s * 3 + 0) * AG + at]; num1 += rsum[(s * 3 + 1) * AG + at]; den += rsum[(s * 3 + 2) * AG + at];
+        }
         bool uniform = false;
         if (in_shape && n_sel > 0) {
             if (den == 0) den = 1E-8;
@@ -371,16 +529,19 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             if (done != nullptr) done[(size_t)e * n_a + i] = 0;                                                         // ENV:480-482
         }
         if (P.export_idx && act) {
+            const short *row = sidx + (size_t)at * P.g_stride;
             int *es_ = P.exp_sensed + ((size_t)e * n_a + i) * G;
             for (int q = 0; q < G; ++q) es_[q] = row[q];
             // occupied list with its own cap, CPP:217-233
+            int n_occ = 0;
+            for (int w = 0; w < W; ++w) n_occ += __popc(obits[w * AG + at]);
             const int O = P.occ_max;
             int *eo = P.exp_occ + ((size_t)e * n_a + i) * O;
             const bool osub = n_occ > O;
             const double ostep = osub ? (double)(n_occ - 1) / (O - 1) : 0.0;
             int os = 0, ok = 0, otarget = 0;
-            for (int w = 0; w < ngwb; ++w) {
-                unsigned it = obits[w * T + tid];
+            for (int w = 0; w < W; ++w) {
+                unsigned it = obits[w * AG + at];
                 while (it) {
                     const int b = __ffs(it) - 1;
                     it &= it - 1;
@@ -392,10 +553,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             for (; os < O; ++os) eo[os] = -1;
         }
     }
-    __syncthreads();
 
     // ---- observation rows, CPP:102-137,274-306: streamed out as (value, value) pairs, consecutive lanes
-    // -> consecutive addresses; the rows of this block's environments are contiguous in HBM.
+    // -> consecutive addresses; the rows of this workgroup's environments are contiguous in HBM.
     if (obs != nullptr) {
         const int PPR = P.obs_dim >> 1;                  // pairs per row
         const int base_pairs = 2 * (P.with_self + P.topo);
@@ -404,11 +564,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         OT2 *out = reinterpret_cast<OT2 *>(obs) + (size_t)blockIdx.x * EPB * n_a * PPR;
         const int dr = T / PPR, dq = T % PPR;
         int r = tid / PPR, q = tid % PPR;
+#pragma unroll 2
         for (int L = tid; L < total; L += T) {
             const int elr = EPB > 1 ? r / n_a : 0;
             const int ir = r - elr * n_a;
             const int tr = elr * NPAD + ir;
-            const double qx = sp[tr], qy = sp[T + tr], ux = sp[2 * T + tr], uy = sp[3 * T + tr];
+            const double qx = sp[tr], qy = sp[AG + tr], ux = sp[2 * AG + tr], uy = sp[3 * AG + tr];
             const int ncf = sncf[tr];
             const double2 *cx = cxy + (size_t)elr * P.cxy_stride;
             double a = 0.0, b = 0.0;
@@ -420,9 +581,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const int j = snei[tr * kTopoMax + (blk - P.with_self)];
                     if (j >= 0) {
                         const int tj = elr * NPAD + j;
-                        if (half) { a = sp[2 * T + tj] - ux; b = sp[3 * T + tj] - uy; }     // CPP:80-81
+                        if (half) { a = sp[2 * AG + tj] - ux; b = sp[3 * AG + tj] - uy; }     // CPP:80-81
                         else {
-                            a = sp[tj] - qx; b = sp[T + tj] - qy;                           // CPP:79
+                            a = sp[tj] - qx; b = sp[AG + tj] - qy;                           // CPP:79
                             if (P.periodic) wrap_rel(a, b, P.w_half, P.h_half);
                         }
                     }
@@ -443,6 +604,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             if (q >= PPR) { q -= PPR; ++r; }
         }
     }
+    STAMP(7);
+#ifdef SWARM_STAMPS
+    if (P.stamps != nullptr && tid == 0)
+        for (int k = 0; k < 8; ++k) P.stamps[(size_t)blockIdx.x * 8 + k] = stamp_t[k];
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -481,6 +647,7 @@ struct swarm_env {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool have_cells, have_state, observed;
+    int attr_smem[4];
     std::vector<char> cells_set;
     std::string err;
     // device buffers
@@ -514,11 +681,10 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-void layout(KP &k, int npad)
+template <int NPAD>
+void layout_t(KP &k)
 {
-    const int T = npad < 64 ? 64 : npad;
-    const int EPB = npad < 64 ? 64 / npad : 1;
-    const int NW = T / 64;
+    constexpr int AG = Geo<NPAD>::AG, EPB = Geo<NPAD>::EPB, NW = Geo<NPAD>::NW, WPE = Geo<NPAD>::WPE;
     k.ngw = (k.ng_max + 31) / 32;
     k.cxy_stride = k.ngw * 32 + 1;            // +1 pair: envs of one wave start on different LDS banks
     int half = (k.g_max + 1) / 2;
@@ -526,27 +692,46 @@ void layout(KP &k, int npad)
     k.g_stride = 2 * half;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~size_t(15); return (int)o; };
+    auto max2 = [](size_t a, size_t b) { return a > b ? a : b; };
     k.off_cxy = take((size_t)EPB * k.cxy_stride * 16);
-    k.off_sp = take((size_t)4 * T * 8);
-    k.off_cmask = take((size_t)((k.ngw + 1) / 2) * 64 * NW * 8);
-    k.off_sbits = take((size_t)k.ngw * T * 4);
-    k.off_obits = take((size_t)k.ngw * T * 4);
-    k.off_sidx = take((size_t)T * k.g_stride * 2);
-    k.off_snei = take((size_t)T * kTopoMax * 2);
-    k.off_sncf = take((size_t)T * 4);
+    k.off_sp = take((size_t)4 * AG * 8);
+    k.off_cmask = take(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 8));      // cmask | rsum
+    k.off_sbits = take((size_t)k.ngw * AG * 4);
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * AG * 12));          // sidx | part_d, part_c
+    k.off_snei = take((size_t)AG * kTopoMax * 2);
+    k.off_sncf = take((size_t)AG * 4);
+    k.off_snear = take((size_t)NW * AG * 8);
+    k.off_pc = take((size_t)k.ngw * AG);
     k.smem_bytes = (int)off;
+    k.off_obits = take((size_t)k.ngw * AG * 4);      // only launches that export the index scratch use it
+    k.smem_bytes_export = (int)off;
+}
+
+void layout(KP &k, int npad)
+{
+    switch (npad) {
+    case 8: layout_t<8>(k); break;
+    case 16: layout_t<16>(k); break;
+    case 32: layout_t<32>(k); break;
+    case 64: layout_t<64>(k); break;
+    case 128: layout_t<128>(k); break;
+    default: layout_t<256>(k); break;
+    }
 }
 
 template <int NPAD, typename OT, bool DO_STEP>
 int launch_t(swarm_env *h, const void *action, int act_f64, void *obs, float *reward, uint8_t *done, void *a_prior)
 {
-    constexpr int T = NPAD < 64 ? 64 : NPAD;
-    constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
+    constexpr int T = Geo<NPAD>::T, EPB = Geo<NPAD>::EPB;
     auto kern = k_env<NPAD, OT, DO_STEP>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   h->kp.smem_bytes));
+    const int smem = h->kp.export_idx ? h->kp.smem_bytes_export : h->kp.smem_bytes;
+    int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : 0)];   // raise the dynamic-LDS cap once per size
+    if (attr < smem) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = smem;
+    }
     const int grid = (h->cfg.n_env + EPB - 1) / EPB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), h->kp.smem_bytes, h->stream, h->kp, action, act_f64,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), smem, h->stream, h->kp, action, act_f64,
                        static_cast<OT *>(obs), reward, done, static_cast<OT *>(a_prior));
     HIP_TRY(h, hipGetLastError());
     return SWARM_OK;
@@ -625,6 +810,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     if (!h) return fail(nullptr, SWARM_ERR_INVALID, "out of host memory");
     h->cfg = *cfg; h->device = dev; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
     h->have_cells = h->have_state = h->observed = false;
+    for (int &a : h->attr_smem) a = -1;
     h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr;
     h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr;
     h->cells_set.assign((size_t)cfg->n_env, 0);
@@ -654,7 +840,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     if (!g.ok) { delete h; return fail(nullptr, SWARM_ERR_HIP, "hipSetDevice failed"); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(nullptr, SWARM_ERR_HIP, "hipGetDeviceProperties failed"); }
-    if ((size_t)k.smem_bytes > (size_t)prop.sharedMemPerBlock && (size_t)k.smem_bytes > 160 * 1024) {
+    if ((size_t)k.smem_bytes_export > 160 * 1024) {
         delete h;
         return fail(nullptr, SWARM_ERR_INVALID, "configuration needs more LDS per workgroup than the device has (reduce n_cells_max / num_obs_grid_max)");
     }
@@ -840,5 +1026,27 @@ int swarm_timer_stop(swarm_env_t *h, float *ms)
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
     return SWARM_OK;
 }
+
+
+#ifdef SWARM_STAMPS
+// Diagnostic build only: run one step with per-block phase clocks; out[grid][8] (host), returns grid size.
+int swarm_debug_stamps(swarm_env_t *h, const void *action, int action_dtype, void *obs, float *reward, uint8_t *done,
+                       void *a_prior, long long *out, int max_blocks)
+{
+    if (!h || !out) return -1;
+    DeviceGuard g(h->device);
+    const int epb = h->npad < 64 ? 64 / h->npad : 1;
+    const int grid = (h->cfg.n_env + epb - 1) / epb;   // same for every Geo<NPAD>
+    if (grid > max_blocks) return -1;
+    long long *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)grid * 8 * sizeof(long long)) != hipSuccess) return -1;
+    h->kp.stamps = d;
+    int rc = launch(h, true, action, action_dtype == SWARM_F64, obs, reward, done, a_prior);
+    h->kp.stamps = nullptr;
+    if (rc == SWARM_OK && hipMemcpy(out, d, (size_t)grid * 8 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+    (void)hipFree(d);
+    return rc == SWARM_OK ? grid : -1;
+}
+#endif
 
 }  // extern "C"
