@@ -1,0 +1,342 @@
+"""Host-side mirror of the reference's env interface for the step path.
+
+`AssemblySwarmEnv` keeps the surface `marl_llm/train`, `marl_llm/eval` and `AssemblySwarmWrapper` rely on
+(/root/reference/cus_gym/gym/envs/customized_envs/assembly.py:15-223,487-666 and
+/root/reference/cus_gym/gym/wrappers/customized_envs/assembly_wrapper.py:18-46; the full list is SURVEY.md
+section 8b): late configuration through ``__reinit__(args)`` with the same attribute names, ``reset() -> obs``,
+``step(a) -> (obs, rew, done, info, a_prior)``, ``n_a / num_agents / agents / agent_types / observation_space /
+action_space / alpha / p / dp / grid_center ...``.  Underneath, E independent environments live on one GPU behind
+``marl_llm_amd.batched.SwarmBatch``; nothing here computes env arithmetic on the CPU except the reset-time
+random draws (host numpy, same draw order as assembly.py:156-219, then uploaded).
+
+Presentation modes
+  * ``n_envs == 1``: exactly the reference's shapes -- obs ``(obs_dim, n_a)``, action ``(2, n_a)``.
+  * ``n_envs == E > 1``, numpy API: the E environments are presented as ONE env with ``n_a = E * N`` agents on the
+    agent axis (env-major), which is what lets the unchanged trainer batch them through its shared policy
+    (SURVEY.md section 7.4 item 5).  ``r_avoid`` is derived from the per-environment N (assembly.py:124).
+  * tensor API (``reset_tensor`` / ``step_tensor``): device tensors ``[E, N, D]`` -- no host round trip.
+"""
+import types
+
+import numpy as np
+
+from .shapes import load_results
+
+try:  # the reference vendors a gym 0.19 fork; when it (or any gym) is importable we subclass it
+    import gym as _gym
+    from gym import spaces as _spaces
+    _EnvBase = _gym.Env
+    _WrapperBase = _gym.Wrapper
+except Exception:  # pragma: no cover - gym absent: minimal stand-ins with the attributes consumers read
+    _gym = None
+    _spaces = None
+    _EnvBase = object
+    _WrapperBase = object
+
+
+class _Box:
+    """Stand-in for gym.spaces.Box when gym is not importable (only .shape/.dtype/.low/.high are consumed)."""
+
+    def __init__(self, low, high, shape, dtype):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
+
+
+def _box(shape):
+    if _spaces is not None:
+        return _spaces.Box(low=-np.inf, high=+np.inf, shape=shape, dtype=np.float32)      # assembly.py:802,806
+    return _Box(-np.inf, np.inf, shape, np.float32)
+
+
+class Agent:                                    # assembly_wrapper.py:5-16
+    def __init__(self, adversary=False):
+        self.adversary = adversary
+
+
+class AssemblySwarmEnv(_EnvBase):
+    metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 45}
+
+    def __init__(self, n_envs=1, device="cuda:0", obs_dtype="float64", rng="global", seed=226):
+        # constants of assembly.py:18-81
+        self.reward_sharing_mode = "individual"
+        self.penalize_entering = self.penalize_interaction = self.penalize_exploration = True
+        self.dim = 2
+        self.n_a = 10
+        self.topo_nei_max = 6
+        self.act_dim_agent = self.dim
+        self.m_a = 1
+        self.size_a = 0.035
+        self.d_sen = 3
+        self.r_avoid = 0.15
+        self.Vel_max = 0.8
+        self.boundary_width_half = self.boundary_height_half = 2.4
+        self.k_ball, self.k_wall, self.c_wall = 30, 100, 5
+        self.dt = 0.1
+        self.n_frames = 1
+        self.sensitivity = 1
+        self.simulation_time = 0
+        self.n_envs = int(n_envs)
+        self._device = device
+        self._obs_dtype = obs_dtype
+        self._rng_mode = rng
+        self._seed = seed
+        self._batch = None
+        self._cells_dirty = False
+
+    # ------------------------------------------------------------------ configuration (assembly.py:92-154)
+    def __reinit__(self, args):
+        self.n_agents_per_env = int(args.n_a)
+        self.n_a = self.n_agents_per_env * self.n_envs           # presented agent axis
+        self.render_traj = getattr(args, "render_traj", False)
+        self.traj_len = getattr(args, "traj_len", 15)
+        self.is_collected = getattr(args, "is_collected", False)
+        self.video = getattr(args, "video", False)
+        self.is_boundary = bool(args.is_boundary)
+        self.is_periodic = not self.is_boundary
+        self.dynamics_mode = args.dynamics_mode
+        self.agent_strategy = args.agent_strategy
+        self.is_con_self_state = bool(args.is_con_self_state)
+        self.is_feature_norm = bool(getattr(args, "is_feature_norm", False))
+        self.training_method = args.training_method
+        self.alpha = 1
+        if self.dynamics_mode != "Cartesian":
+            raise ValueError("only dynamics_mode='Cartesian' exists in the reference (assembly.py:141-146)")
+        if self.agent_strategy != "input":
+            raise NotImplementedError("agent_strategy %r: only 'input' is on the GPU path" % (self.agent_strategy,))
+        if self.is_collected:
+            raise NotImplementedError("is_collected (rule-based expert collection) is not on the GPU path yet")
+
+        results = args.results_file if isinstance(args.results_file, dict) else load_results(args.results_file)
+        self.l_cells = list(results["l_cell"])
+        self.grid_center_origins = [np.asarray(g, dtype=np.float64) for g in results["grid_coords"]]
+        self.binary_images = results.get("binary_image", [None] * len(self.l_cells))
+        self.shape_bound_points_origins = results.get("shape_bound_points", [np.zeros(4)] * len(self.l_cells))
+        self.num_train_shape = len(self.l_cells)
+        self.n_gs = [g.shape[0] for g in self.grid_center_origins]
+        self.r_avoid = round(float(np.sqrt(4 * np.min(self.n_gs) / (self.n_agents_per_env * np.pi)) * np.min(self.l_cells)), 2)
+        self.num_obs_grid_max = 80
+        self.num_occupied_grid_max = 200
+        if self._rng_mode == "global":
+            np.random.choice([True, False], size=(self.n_agents_per_env, self.n_agents_per_env))   # assembly.py:133 (draws kept)
+        self.obs_dim_agent = 2 * self.dim * (self.topo_nei_max + 1 + int(self.is_con_self_state)) + self.dim * self.num_obs_grid_max
+        self.observation_space = _box((self.obs_dim_agent, self.n_a))
+        self.action_space = _box((self.act_dim_agent, self.n_a))
+        self.shape_frequency = np.zeros(len(self.l_cells))
+        self.n_cells_max = int(max(self.n_gs))
+        self._batch = None
+
+    # ------------------------------------------------------------------ backend
+    def _backend(self):
+        if self._batch is None:
+            import torch
+            from .batched import SwarmBatch
+            dt = torch.float64 if self._obs_dtype in ("float64", "f64") else torch.float32
+            self._batch = SwarmBatch(n_env=self.n_envs, n_agents=self.n_agents_per_env, n_cells_max=self.n_cells_max,
+                                     r_avoid=self.r_avoid, is_boundary=self.is_boundary,
+                                     with_self=self.is_con_self_state, with_prior=(self.training_method == "llm_rl"),
+                                     obs_dtype=dt, device=self._device, d_sen=0.4,
+                                     topo=self.topo_nei_max, g_max=self.num_obs_grid_max,
+                                     occ_max=self.num_occupied_grid_max,
+                                     boundary=(-self.boundary_width_half, self.boundary_height_half,
+                                               self.boundary_width_half, -self.boundary_height_half),
+                                     size_a=self.size_a, k_ball=self.k_ball, k_wall=self.k_wall, c_wall=self.c_wall,
+                                     vel_max=self.Vel_max, dt=self.dt)
+        return self._batch
+
+    # ------------------------------------------------------------------ reset (assembly.py:156-223)
+    def _sample_reset(self):
+        """Host-side random draws of reset(), per environment, in the reference's order.  Pure numpy (no GPU)."""
+        E, N = self.n_envs, self.n_agents_per_env
+        W, H = self.boundary_width_half, self.boundary_height_half
+        cells = np.zeros((E, 2, self.n_cells_max)); n_g = np.zeros(E, np.int32); l_cell = np.zeros(E)
+        p = np.zeros((E, 2, N)); dp = np.zeros((E, 2, N))
+        shape_idx = np.zeros(E, np.int64)
+        for e in range(E):
+            rs = np.random if self._rng_mode == "global" else np.random.RandomState([self._seed, self._episode, e])
+            s = rs.randint(0, self.num_train_shape)                                   # :160
+            self.shape_frequency[s] += 1
+            origin = self.grid_center_origins[s].T                                    # :164
+            ang = np.pi * rs.uniform(-1, 1)                                           # :175
+            rot = np.array([[np.cos(ang), np.sin(ang)], [-np.sin(ang), np.cos(ang)]])
+            origin = np.dot(rot, 1 * origin)                                          # :170-178 (shape_scale = 1)
+            rs.uniform(-1.2, 1.2, (2, 1))                                             # :182 drawn, then discarded
+            off = np.array([[rs.uniform(-W + 1, W - 1), rs.uniform(-H + 1, H - 1)]]).T   # :184-185
+            g = origin.copy() + off                                                   # :187
+            if rs.uniform(-1, 1) > 0:                                                 # :202-208
+                pe = np.concatenate((rs.uniform(-W, W, (1, N)), rs.uniform(-H, H, (1, N))), axis=0)
+            else:
+                pe = rs.uniform(-1, 1, (2, N)) + np.array([[rs.uniform(-W + 1, W - 1), rs.uniform(-H + 1, H - 1)]]).T
+            dpe = rs.uniform(-0.5, 0.5, (2, N))                                       # :215
+            ng = g.shape[1]
+            cells[e, :, :ng] = g; n_g[e] = ng; l_cell[e] = 1 * self.l_cells[s]
+            p[e] = pe; dp[e] = dpe; shape_idx[e] = s
+        return dict(cells=cells, n_g=n_g, l_cell=l_cell, p=p, dp=dp, shape_index=shape_idx)
+
+    def reset_tensor(self):
+        """reset() returning the device observation tensor [E, N, D]."""
+        self.simulation_time = 0
+        self._episode = getattr(self, "_episode", -1) + 1
+        s = self._sample_reset()
+        self._cells, self._n_g, self._l_cell = s["cells"], s["n_g"], s["l_cell"]
+        self.shape_index = s["shape_index"]
+        self.d_sen = 0.4                                                              # :199
+        self.boundary_pos = np.array([-self.boundary_width_half, self.boundary_height_half,
+                                      self.boundary_width_half, -self.boundary_height_half], dtype=np.float64)
+        b = self._backend()
+        b.set_cells(self._cells, self._n_g, self._l_cell)
+        b.set_state(s["p"], s["dp"])
+        self._cells_dirty = False
+        return b.observe()
+
+    def reset(self):
+        return self._obs_to_numpy(self.reset_tensor())
+
+    # ------------------------------------------------------------------ step (assembly.py:487-666)
+    def step_tensor(self, action):
+        """action [E, N, 2] device tensor -> (obs [E,N,D], reward [E,N], done [E,N] uint8, a_prior [E,N,2] | None)."""
+        b = self._backend()
+        if self._cells_dirty:          # eval-time shape switch (eval_assembly.py:34-57): refresh cells + caches
+            b.set_cells(self._cells, self._n_g, self._l_cell)
+            b.observe()
+            self._cells_dirty = False
+        self.simulation_time += self.dt
+        return b.step(action)
+
+    def step(self, a):
+        import torch
+        E, N = self.n_envs, self.n_agents_per_env
+        a = np.asarray(a)
+        if a.shape != (self.act_dim_agent, self.n_a):
+            raise ValueError("action must have shape %r" % ((self.act_dim_agent, self.n_a),))
+        dt = torch.float64 if a.dtype == np.float64 else torch.float32
+        act = torch.as_tensor(np.ascontiguousarray(a.T.reshape(E, N, 2)), dtype=dt, device=self._backend().device)
+        obs, rew, done, pri = self.step_tensor(act)
+        obs_np = self._obs_to_numpy(obs)
+        rew_np = rew.reshape(1, E * N).to(torch.float64).cpu().numpy()                # (1, n_a), assembly.py:353
+        done_np = done.reshape(1, E * N).cpu().numpy().astype(bool)                   # (1, n_a) bool, :480-482
+        info = np.array([None, None, None]).reshape(3, 1)                             # :484-485
+        pri_np = None
+        if pri is not None:
+            pri_np = np.ascontiguousarray(pri.reshape(E * N, 2).to(torch.float64).cpu().numpy().T)   # (2, n_a)
+        return obs_np, rew_np, done_np, info, pri_np
+
+    def _obs_to_numpy(self, obs):
+        E, N = self.n_envs, self.n_agents_per_env
+        return np.ascontiguousarray(obs.reshape(E * N, self.obs_dim_agent).cpu().numpy().astype(np.float64).T)
+
+    # ------------------------------------------------------------------ state the reference exposes as attributes
+    @property
+    def p(self):
+        """(2, n_a) positions, env-major on the agent axis (eval_assembly.py:137,150 reads env.p)."""
+        p, _ = self._backend().get_state()
+        return np.ascontiguousarray(p.cpu().numpy().transpose(1, 0, 2).reshape(2, -1))
+
+    @property
+    def dp(self):
+        _, dp = self._backend().get_state()
+        return np.ascontiguousarray(dp.cpu().numpy().transpose(1, 0, 2).reshape(2, -1))
+
+    def set_state(self, p, dp):
+        """Inject a state ((2, n_a) arrays or [E,2,N]); recomputes the obs-derived caches.  Returns obs."""
+        E, N = self.n_envs, self.n_agents_per_env
+        p = np.asarray(p, np.float64); dp = np.asarray(dp, np.float64)
+        if p.ndim == 2:
+            p = p.reshape(2, E, N).transpose(1, 0, 2); dp = dp.reshape(2, E, N).transpose(1, 0, 2)
+        b = self._backend()
+        b.set_state(np.ascontiguousarray(p), np.ascontiguousarray(dp))
+        return self._obs_to_numpy(b.observe())
+
+    def indices(self):
+        """neighbor_index / in_flags / sensed_index / occupied_index of the current state (numpy)."""
+        return {k: v.cpu().numpy() for k, v in self._backend().indices().items()}
+
+    # grid_center / n_g / l_cell: readable and writable like the reference's attributes (env 0 when E > 1)
+    @property
+    def grid_center(self):
+        return np.ascontiguousarray(self._cells[0][:, : self._n_g[0]])
+
+    @grid_center.setter
+    def grid_center(self, g):
+        g = np.asarray(g, np.float64)
+        if g.shape[1] > self.n_cells_max:
+            raise ValueError("grid_center has more cells than n_cells_max=%d" % self.n_cells_max)
+        self._cells[:, :, :] = 0.0
+        self._cells[:, :, : g.shape[1]] = g
+        self._n_g[:] = g.shape[1]
+        self._cells_dirty = True
+
+    @property
+    def n_g(self):
+        return int(self._n_g[0])
+
+    @n_g.setter
+    def n_g(self, v):
+        self._n_g[:] = int(v); self._cells_dirty = True
+
+    @property
+    def l_cell(self):
+        return float(self._l_cell[0])
+
+    @l_cell.setter
+    def l_cell(self, v):
+        self._l_cell[:] = float(v); self._cells_dirty = True
+
+    # ------------------------------------------------------------------ misc gym surface
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is outside the step path (SURVEY.md section 8: out of scope)")
+
+    def close(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+class AssemblySwarmWrapper(_WrapperBase):
+    """assembly_wrapper.py:18-46: calls env.__reinit__(args) and exposes the multi-agent attributes."""
+
+    def __init__(self, env, args):
+        if _WrapperBase is not object:
+            super().__init__(env)
+        else:
+            self.env = env
+        env.__reinit__(args)
+        self.num_agents = self.env.n_a
+        self.agents = [Agent() for _ in range(self.num_agents)]
+        self.agent_types = ["agent"]
+        self.action_space = self.env.action_space
+        self.observation_space = self.env.observation_space
+
+    def __getattr__(self, name):                 # gym.Wrapper forwards reads the same way (core.py:232-238)
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    def reset(self, **kw):
+        return self.env.reset(**kw)
+
+    def step(self, a):
+        return self.env.step(a)
+
+
+def make_args(n_a=30, results_file=None, **over):
+    """The env-relevant flags of marl_llm/cfg/assembly_cfg.py:153-168 with their defaults."""
+    d = dict(n_a=n_a, is_boundary=True, is_con_self_state=True, is_feature_norm=False, dynamics_mode="Cartesian",
+             render_traj=False, traj_len=15, agent_strategy="input", training_method="llm_rl", is_collected=False,
+             results_file=results_file, video=False)
+    d.update(over)
+    return types.SimpleNamespace(**d)
+
+
+def register(gym_module=None, n_envs=1, **kw):
+    """Register 'AssemblySwarm-v0' in a gym registry so `gym.make('AssemblySwarm-v0').unwrapped`
+    (train_assembly.py:49) yields this env."""
+    g = gym_module or _gym
+    if g is None:
+        raise RuntimeError("no gym module to register into")
+    from gym.envs.registration import register as _reg, registry
+    if "AssemblySwarm-v0" in getattr(registry, "env_specs", {}):
+        del registry.env_specs["AssemblySwarm-v0"]
+    _reg(id="AssemblySwarm-v0", entry_point="marl_llm_amd.env:AssemblySwarmEnv", kwargs=dict(n_envs=n_envs, **kw))
