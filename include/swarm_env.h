@@ -85,7 +85,7 @@ typedef struct swarm_config {
     int32_t with_prior;             /* training_method == 'llm_rl': compute a_prior (assembly.py:605-624) */
     int32_t obs_dtype;              /* SWARM_F32 (product) or SWARM_F64 (bit-exact parity mode) */
     int32_t device;                 /* HIP device ordinal, -1 = current */
-    int32_t reserved;
+    int32_t debug_flags;            /* bit 0: force every exact (fp64) fallback path of the fp32 pre-filters */
     double d_sen;                   /* assembly.py:199  = 0.4 */
     double r_avoid;                 /* assembly.py:124 */
     double size_a;                  /* assembly.py:44   = 0.035 */

@@ -13,7 +13,7 @@ class SwarmConfig(ctypes.Structure):
                 ("topo_nei_max", ctypes.c_int32), ("num_obs_grid_max", ctypes.c_int32),
                 ("num_occupied_grid_max", ctypes.c_int32), ("is_boundary", ctypes.c_int32),
                 ("with_self_state", ctypes.c_int32), ("with_prior", ctypes.c_int32), ("obs_dtype", ctypes.c_int32),
-                ("device", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("debug_flags", ctypes.c_int32),
                 ("d_sen", ctypes.c_double), ("r_avoid", ctypes.c_double), ("size_a", ctypes.c_double),
                 ("k_ball", ctypes.c_double), ("k_wall", ctypes.c_double), ("c_wall", ctypes.c_double),
                 ("vel_max", ctypes.c_double), ("dt", ctypes.c_double), ("boundary", ctypes.c_double * 4)]

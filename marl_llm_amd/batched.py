@@ -20,7 +20,7 @@ class SwarmBatch:
     def __init__(self, n_env, n_agents, n_cells_max, r_avoid, *, is_boundary=True, with_self=True, with_prior=True,
                  obs_dtype=torch.float32, device="cuda:0", d_sen=0.4, topo=6, g_max=80, occ_max=200,
                  boundary=(-2.4, 2.4, 2.4, -2.4), size_a=0.035, k_ball=30.0, k_wall=100.0, c_wall=5.0,
-                 vel_max=0.8, dt=0.1):
+                 vel_max=0.8, dt=0.1, debug_flags=0):
         if not torch.cuda.is_available():
             raise SwarmError("no HIP device visible to PyTorch: the env step has no CPU fallback")
         self.lib = _lib.load()
@@ -38,6 +38,7 @@ class SwarmBatch:
             raise SwarmError("obs_dtype must be torch.float32 or torch.float64")
         cfg.obs_dtype = F64 if obs_dtype == torch.float64 else F32
         cfg.device = dev_index
+        cfg.debug_flags = int(debug_flags)
         cfg.d_sen, cfg.r_avoid, cfg.size_a = float(d_sen), float(r_avoid), float(size_a)
         cfg.k_ball, cfg.k_wall, cfg.c_wall, cfg.vel_max, cfg.dt = float(k_ball), float(k_wall), float(c_wall), float(vel_max), float(dt)
         for k in range(4):

@@ -32,6 +32,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "swarm_env.h"
@@ -39,16 +41,29 @@
 namespace {
 
 constexpr int kTopoMax = 6;
+constexpr int kNeiStride = 8;     // shorts per agent in the LDS neighbour list: 6 ids, [6] = collision flag
 typedef unsigned long long u64;
 
 struct KP {
     int n_env, n_a, ng_max, ngw, topo, g_max, occ_max, obs_dim;
     int with_self, periodic, boundary, with_prior, export_idx;
     int cxy_stride;            // double2 elements per env in LDS
+    int cxq_stride;            // floats per env in the fp32 pair layout
     int g_stride;              // int16 elements per agent row in LDS
     int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear, off_pc;
     int smem_bytes, smem_bytes_export;
     double c_sen, c_near, c_occ, c_avoid, c_ball;     // squared-distance cut-offs
+    // fp32 pre-filter bands: d2_32 < *_lo  =>  exact test true;  d2_32 >= *_hi  =>  exact test false
+    float csen_lo, csen_hi, cocc_lo, cocc_hi;
+    float coord_lim;           // |coordinate| bound the bands were derived for
+    float min_tol_a, min_tol_b;   // nearest-cell ambiguity tolerance: a*sqrt(d2) + b*d2
+    float rew_guard;           // |v| band around 0.05 inside which the reward is re-evaluated in fp64
+    int force_exact;           // debug: take every exact fallback path
+    int cap_int;               // G-1 odd: the cap's round(i*step) is an exact integer division by 2(G-1)
+    unsigned cap_magic; int cap_shift;
+    int dbg_phase, dbg_extra;  // diagnostics only (tools/ablate.py): run phase dbg_phase dbg_extra EXTRA times; the
+                               // phases are idempotent, so results are unchanged and the extra cost is the phase's cost
+    int off_cxyf;
     double d_sen, r_avoid, size_a, size2, k_ball, k_wall, c_wall, vel_max, dt;
     double bx0, by1, bx2, by3, w_half, h_half;
     double *p, *dp;
@@ -60,6 +75,8 @@ struct KP {
     long long *stamps;         // diagnostic build only (-DSWARM_STAMPS): per-block phase clocks
 };
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 template <typename T> struct Pair;
 template <> struct Pair<float>  { typedef float2 type; };
 template <> struct Pair<double> { typedef double2 type; };
@@ -70,11 +87,44 @@ __device__ __forceinline__ void wrap_rel(double &x, double &y, double wh, double
     if (y < -hh) y += 2 * hh; else if (y > hh) y -= 2 * hh;
 }
 
+// old[LANE] = value (wave-uniform value, compile-time lane): one v_writelane_b32 (the lane select must be an
+// inline constant: a second SGPR operand would violate the constant-bus limit).
+template <int LANE>
+__device__ __forceinline__ int writelane_c(int value, int old)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
+    return old;
+}
+
+// (acc << 1) | bit, the bit coming per lane from a 64-bit lane mask (a compare result): ONE v_addc_co_u32 with
+// the mask as carry-in.
+__device__ __forceinline__ unsigned shl1_or_mask(unsigned acc, unsigned long long mask)
+{
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(mask));
+    return acc;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
 __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
 {   // CPP:11-14  std::max(lo, std::min(v, hi))
     double m = (hi < v) ? hi : v;
     return (lo < m) ? m : lo;
 }
+
+#define REPS(k) ((P.dbg_phase == (k)) ? P.dbg_extra + 1 : 1)
+#define FENCE() asm volatile("" ::: "memory")
 
 #ifdef SWARM_STAMPS
 #define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); stamp_t[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -121,6 +171,21 @@ __device__ __forceinline__ double cospi01(double t)
     return flip ? -c : c;
 }
 
+// fp32 fast path of the reward weight: psi(u) = 1/2 (1 + cos(pi sqrt(u))), u = (z/d_sen)^2 in [0, 1], as a
+// degree-6 minimax polynomial in u (cos(pi sqrt(u)) is entire in u): no sqrt, no range reduction.
+// |abs err| < 3e-7 in fp32 Horner form (fit error 5.5e-9).
+__device__ __forceinline__ float psi_u_f32(float u)
+{
+    float c = 7.969553699e-04f;
+    c = fmaf(c, u, -1.267949212e-02f);
+    c = fmaf(c, u, 1.175149009e-01f);
+    c = fmaf(c, u, -6.675792336e-01f);
+    c = fmaf(c, u, 2.029347420e+00f);
+    c = fmaf(c, u, -2.467400551e+00f);
+    c = fmaf(c, u, 1.0f);
+    return c;
+}
+
 template <int NPAD, typename OT, bool DO_STEP>
 __global__ void __launch_bounds__(Geo<NPAD>::T)
 k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__restrict__ obs,
@@ -131,22 +196,22 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *cxy = reinterpret_cast<double2 *>(smem + P.off_cxy);
+    float *cxq = reinterpret_cast<float *>(smem + P.off_cxyf);          // fp32 cells, per PAIR {xa, xb, ya, yb} (pre-filter)
     double *sp = reinterpret_cast<double *>(smem + P.off_sp);            // [4][AG]: px, py, vx, vy
     u64 *cmask = reinterpret_cast<u64 *>(smem + P.off_cmask);            // [cell][NW]
-    double *rsum = reinterpret_cast<double *>(smem + P.off_cmask);       // [WPE][3][AG]  (aliases cmask, later phase)
+    float *rsum = reinterpret_cast<float *>(smem + P.off_cmask);         // [WPE][3][AG]  (aliases cmask, later phase)
     unsigned *sbits = reinterpret_cast<unsigned *>(smem + P.off_sbits);  // [word][AG]
     unsigned *obits = reinterpret_cast<unsigned *>(smem + P.off_obits);  // [word][AG] (export launches only)
     short *sidx = reinterpret_cast<short *>(smem + P.off_sidx);          // [AG][g_stride]
-    double *part_d = reinterpret_cast<double *>(smem + P.off_sidx);      // [WPE][AG]     (aliases sidx, earlier phase)
-    int *part_c = reinterpret_cast<int *>(smem + P.off_sidx + (size_t)WPE * AG * 8);   // [WPE][AG]
+    int *part_c = reinterpret_cast<int *>(smem + P.off_sidx);            // [WPE][AG]     (aliases sidx, earlier phase)
     short *snei = reinterpret_cast<short *>(smem + P.off_snei);          // [AG][kTopoMax]
     int *sncf = reinterpret_cast<int *>(smem + P.off_sncf);              // [AG]: nearest cell | in_flag<<30
     u64 *snear = reinterpret_cast<u64 *>(smem + P.off_snear);            // [NW][AG] nearby-agent masks
     unsigned char *pc = smem + P.off_pc;                                 // [word][AG] kept-bit counts
 
 #ifdef SWARM_STAMPS
-    long long stamp_t[10];
-    for (int k = 0; k < 10; ++k) stamp_t[k] = 0;
+    long long stamp_t[16];
+    for (int k = 0; k < 16; ++k) stamp_t[k] = 0;
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     STAMP(0);
@@ -169,16 +234,45 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     const int W = (ngb + 31) >> 5;                       // target-cell words of this workgroup
-    // words [0, w0) belong to split 0, the rest are dealt round-robin to splits 1..WPE-1
+    // Split roles: split 0 ("A") = forces / integration / reward combine; split SB ("B") = prior policy and
+    // neighbour search, which run concurrently with A's work; every split scans target-cell words.  Words
+    // [0, w0) belong to split B (it gets fewer), the rest are dealt round-robin to the other splits.
+    constexpr int SB = WPE > 1 ? 1 : 0;
     int w0 = W;
-    if (WPE > 1) { w0 = (W - (DO_STEP ? 3 : 2) * (WPE - 1)) / WPE; w0 = w0 < 0 ? 0 : w0; }
+    if (WPE > 1) { w0 = (W - 2 * (WPE - 1)) / WPE; w0 = w0 < 0 ? 0 : w0; }
     auto mine = [&](int w) -> bool {
         if (WPE == 1) return true;
-        return w < w0 ? (sx == 0) : (sx == 1 + (w - w0) % (WPE - 1));
+        if (w < w0) return sx == SB;
+        const int o = (w - w0) % (WPE - 1);            // o-th of the non-B splits
+        return sx == (o < SB ? o : o + 1);
     };
     double2 *cxy_e = cxy + (size_t)el * P.cxy_stride;
+    const float *cq_e = cxq + (size_t)el * P.cxq_stride;
 
-    // ---- stage the target cells (ENV: grid_center (2, n_g)) in LDS as (x, y) pairs; pad with a sentinel
+    // ---- issue every global load of the step up front (their latency overlaps the cell staging)
+    const size_t sbase = (size_t)es * 2 * n_a;
+    double px = __builtin_nan(""), py = __builtin_nan(""), vx = 0.0, vy = 0.0;   // inactive lanes: NaN positions,
+    double ax = 0.0, ay = 0.0;                                                    // every comparison is false
+    int pj[kTopoMax]; int ncell = 0, inf = 0;
+#pragma unroll
+    for (int k = 0; k < kTopoMax; ++k) pj[k] = -1;
+    if (sx == 0 && act) {
+        px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
+        vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
+        if (DO_STEP) {
+            if (act_f64) { const size_t ab = ((size_t)e * n_a + i) * 2; ax = ((const double *)action)[ab]; ay = ((const double *)action)[ab + 1]; }
+            else { const float2 af = reinterpret_cast<const float2 *>(action)[(size_t)e * n_a + i]; ax = (double)af.x; ay = (double)af.y; }
+        }
+    }
+    if (DO_STEP && sx == SB && act && P.with_prior) {
+        ncell = P.near_cell[(size_t)e * n_a + i];
+        inf = P.in_flag[(size_t)e * n_a + i];
+#pragma unroll
+        for (int k = 0; k < kTopoMax; ++k)
+            if (k < P.topo) pj[k] = P.nei[((size_t)e * n_a + i) * P.topo + k];
+    }
+    // ---- stage the target cells (ENV: grid_center (2, n_g)) in LDS: (x, y) f64 pairs and an fp32 copy laid out
+    // per pair of cells {xa, xb, ya, yb} for packed arithmetic; pad with a sentinel (fp32: +inf)
     for (int k = 0; k < EPB; ++k) {
         const int ek0 = blockIdx.x * EPB + k;
         const int ek = ek0 < P.n_env ? ek0 : P.n_env - 1;
@@ -190,82 +284,19 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             g.x = c < ngk ? gx[c] : kSentinel;
             g.y = c < ngk ? gy[c] : kSentinel;
             cxy[(size_t)k * P.cxy_stride + c] = g;
+            float *q = cxq + (size_t)k * P.cxq_stride + (c >> 1) * 4 + (c & 1);
+            q[0] = (float)g.x; q[2] = (float)g.y;
         }
     }
-    // ---- state (inactive lanes carry NaN positions: every comparison with them is false)
-    const size_t sbase = (size_t)es * 2 * n_a;
-    double px = __builtin_nan(""), py = __builtin_nan(""), vx = 0.0, vy = 0.0;
-    if (sx == 0) {
-        if (act) {
-            px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
-            vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
-        }
-        sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy;
-    }
+    if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
     __syncthreads();
     STAMP(1);
 
     if (DO_STEP) {
+        if (sx == SB && SB != 0) { px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at]; }
         double npx = px, npy = py, nvx = vx, nvy = vy;
-        if (sx == 0) {
-            // ---- ball-to-ball contact spring: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all).
-            // Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped when
-            // periodic), d_center un-wrapped for every pair the reference evaluates (its numpy wrap only touches
-            // agent 0's row, which the i>j loop never reads).  Summed over k in index order.
-            // issue every global load of this phase up front so their latency overlaps the contact loop
-            int pj[kTopoMax]; int ncell = 0, inf = 0;
-            double ax = 0.0, ay = 0.0;
-#pragma unroll
-            for (int k = 0; k < kTopoMax; ++k) pj[k] = -1;
-            if (act) {
-                const size_t ab = ((size_t)e * n_a + i) * 2;
-                if (act_f64) { ax = ((const double *)action)[ab]; ay = ((const double *)action)[ab + 1]; }
-                else { const float2 af = reinterpret_cast<const float2 *>(action)[(size_t)e * n_a + i]; ax = (double)af.x; ay = (double)af.y; }
-                if (P.with_prior) {
-                    ncell = P.near_cell[(size_t)e * n_a + i];
-                    inf = P.in_flag[(size_t)e * n_a + i];
-#pragma unroll
-                    for (int k = 0; k < kTopoMax; ++k)
-                        if (k < P.topo) pj[k] = P.nei[((size_t)e * n_a + i) * P.topo + k];
-                }
-            }
-            double sfx = 0.0, sfy = 0.0;
-            {
-                constexpr int KN = NPAD < 64 ? NPAD : 64;       // lanes >= n_a hold NaN positions: never "colliding"
-                const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
-                for (int kb = 0; kb < NW * 64 && kb < NPAD; kb += KN) {
-#pragma unroll 8
-                    for (int kk = 0; kk < KN; ++kk) {
-                        const int k = kb + kk;
-                        const double dx = spx[k] - px, dy = spy[k] - py;
-                        const double d2 = dx * dx + dy * dy;
-                        if (k != i && d2 < P.c_ball) {
-                            const double dc = sqrt(d2);
-                            const double de = fabs(dc - P.size2);
-                            double wx = dx, wy = dy;
-                            if (P.periodic) wrap_rel(wx, wy, P.w_half, P.h_half);
-                            const double ux = wx / dc, uy = wy / dc;
-                            sfx += 1.0 * de * P.k_ball * (-ux);
-                            sfy += 1.0 * de * P.k_ball * (-uy);
-                        }
-                    }
-                }
-            }
-            double Fx = 1 * ax + sfx, Fy = 1 * ay + sfy;                       // ENV:638,640
-            if (P.boundary) {                                                   // CPP:817-855, ENV:515-518
-                const double d0 = px - P.size_a - P.bx0;
-                const double d1 = P.by1 - (py + P.size_a);
-                const double d2 = P.bx2 - (px + P.size_a);
-                const double d3 = py - P.size_a - P.by3;
-                const double a0 = d0 < 0 ? fabs(d0) : 0.0, a1 = d1 < 0 ? fabs(d1) : 0.0;
-                const double a2 = d2 < 0 ? fabs(d2) : 0.0, a3 = d3 < 0 ? fabs(d3) : 0.0;
-                const double sx_ = (a0 - a2) * P.k_wall, sy_ = (a3 - a1) * P.k_wall;
-                const double v0 = d0 < 0 ? vx : 0.0, v2 = d2 < 0 ? vx : 0.0;
-                const double v3 = d3 < 0 ? vy : 0.0, v1 = d1 < 0 ? vy : 0.0;
-                const double gx = (-v0 - v2) * P.c_wall, gy = (-v3 - v1) * P.c_wall;
-                Fx = Fx + sx_ + gx;
-                Fy = Fy + sy_ + gy;
-            }
+        if (sx == SB) for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
+            FENCE();
             // ---- prior policy on the PRE-integration state with the previous neighbour list:
             // CPP:1061-1196 via ENV:605-624.  The nearest cell / in-shape flag of the pre-integration
             // position are the ones the previous observation pass cached.
@@ -298,6 +329,67 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 OT2 o; o.x = (OT)clamp_ref(qx, -1.0, 1.0); o.y = (OT)clamp_ref(qy, -1.0, 1.0);
                 reinterpret_cast<OT2 *>(a_prior)[(size_t)e * n_a + i] = o;
             }
+        }
+        if (sx == 0) for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
+            FENCE();
+            // ---- ball-to-ball contact spring: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all).
+            // Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped when
+            // periodic), d_center un-wrapped for every pair the reference evaluates (its numpy wrap only touches
+            // agent 0's row, which the i>j loop never reads).  Summed over k in index order.
+            double sfx = 0.0, sfy = 0.0;
+            {
+                // pass A (branch-free, unrolled): which agents k overlap agent i (centre distance < 0.07)?
+                // lanes >= n_a hold NaN positions and never compare true.
+                constexpr int KN = NPAD < 64 ? NPAD : 64;
+                const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
+                u64 hit[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    u64 h = 0;
+#pragma unroll 8
+                    for (int kk = 0; kk < KN; ++kk) {
+                        const double dx = spx[w * 64 + kk] - px, dy = spy[w * 64 + kk] - py;
+                        const double d2 = dx * dx + dy * dy;
+                        if (d2 < P.c_ball) h |= 1ull << kk;
+                    }
+                    hit[w] = h;
+                }
+                if (i < 64 * NW) hit[NPAD <= 64 ? 0 : (i >> 6)] &= ~(1ull << (i & 63));       // k != i
+                // pass B: the colliding pairs in ascending k (the reference's summation order, CPP:799-807)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    u64 h = hit[w];
+                    while (h) {
+                        const int kk = __ffsll((unsigned long long)h) - 1;
+                        h &= h - 1;
+                        const double dx = spx[w * 64 + kk] - px, dy = spy[w * 64 + kk] - py;
+                        const double dc = sqrt(dx * dx + dy * dy);
+                        const double de = fabs(dc - P.size2);
+                        double wx = dx, wy = dy;
+                        if (P.periodic) wrap_rel(wx, wy, P.w_half, P.h_half);
+                        const double ux = wx / dc, uy = wy / dc;
+                        sfx += 1.0 * de * P.k_ball * (-ux);
+                        sfy += 1.0 * de * P.k_ball * (-uy);
+                    }
+                }
+            }
+            STAMP(8);
+            double Fx = 1 * ax + sfx, Fy = 1 * ay + sfy;                       // ENV:638,640
+            if (P.boundary) {                                                   // CPP:817-855, ENV:515-518
+                const double d0 = px - P.size_a - P.bx0;
+                const double d1 = P.by1 - (py + P.size_a);
+                const double d2 = P.bx2 - (px + P.size_a);
+                const double d3 = py - P.size_a - P.by3;
+                const double a0 = d0 < 0 ? fabs(d0) : 0.0, a1 = d1 < 0 ? fabs(d1) : 0.0;
+                const double a2 = d2 < 0 ? fabs(d2) : 0.0, a3 = d3 < 0 ? fabs(d3) : 0.0;
+                const double sx_ = (a0 - a2) * P.k_wall, sy_ = (a3 - a1) * P.k_wall;
+                const double v0 = d0 < 0 ? vx : 0.0, v2 = d2 < 0 ? vx : 0.0;
+                const double v3 = d3 < 0 ? vy : 0.0, v1 = d1 < 0 ? vy : 0.0;
+                const double gx = (-v0 - v2) * P.c_wall, gy = (-v3 - v1) * P.c_wall;
+                Fx = Fx + sx_ + gx;
+                Fy = Fy + sy_ + gy;
+            }
+            STAMP(10);
             // ---- integration, ENV:643-652
             nvx = vx + (Fx / 1.0) * P.dt; nvy = vy + (Fy / 1.0) * P.dt;
             nvx = nvx < -P.vel_max ? -P.vel_max : (nvx > P.vel_max ? P.vel_max : nvx);
@@ -310,7 +402,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 if (npy > P.by1) npy -= 2 * P.h_half;
             }
         }
+        STAMP(11);
         __syncthreads();                 // every lane is done with the old positions in LDS
+        STAMP(12);
         if (sx == 0) {
             sp[at] = npx; sp[AG + at] = npy; sp[2 * AG + at] = nvx; sp[3 * AG + at] = nvy;
             if (act) {
@@ -326,87 +420,161 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // ---- neighbour search (split 0), CPP:77-100 + _get_focused CPP:628-698: the topo nearest agents with
     // norm < d_sen (self removed), ascending.  Also the "nearby" agent mask of the occupied-cell filter
     // (CPP:152-164: un-wrapped distance < d_sen + r_avoid/2, self included).
-    bool collision = false;
-    if (sx == 0) {
+    if (sx == SB) for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
+        FENCE();
+        bool collision = false;
         double nd[kTopoMax]; int nj[kTopoMax];
 #pragma unroll
         for (int k = 0; k < kTopoMax; ++k) { nd[k] = INFINITY; nj[k] = -1; }
-        u64 nearby[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) nearby[w] = 0;
+        u64 nearby[NW], cand[NW];
+        constexpr int JN = NPAD < 64 ? NPAD : 64;               // lanes >= n_a hold NaN positions: never candidates
+        const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
+        // pass A (branch-free, unrolled): candidate mask (norm < d_sen, CPP:658) and "nearby" mask (CPP:161)
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            constexpr int JN = NPAD < 64 ? NPAD : 64;           // lanes >= n_a hold NaN positions: never candidates
-            constexpr int JB = 8;
-            const double *spx = sp + el * NPAD + w * 64, *spy = sp + AG + el * NPAD + w * 64;
-            for (int jb = 0; jb < JN; jb += JB) {
-                double d2b[JB];
-                u64 nb = 0;
+            u64 nb = 0, cd = 0;
+#pragma unroll 8
+            for (int jj = 0; jj < JN; ++jj) {
+                double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                const double d2u = rx * rx + ry * ry;
+                if (d2u < P.c_near) nb |= 1ull << jj;
+                double d2 = d2u;
+                if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
+                if (d2 < P.c_sen) cd |= 1ull << jj;
+            }
+            // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
+            nearby[w] = NPAD < 64 ? (nb << (el * NPAD)) : nb;
+            cand[w] = cd;
+        }
+        if (i < 64 * NW) cand[NPAD <= 64 ? 0 : (i >> 6)] &= ~(1ull << (i & 63));             // remove self (CPP:672-676)
+        // pass B: ordered insertion of the candidates, ascending j => ties keep the lower index first
 #pragma unroll
-                for (int q = 0; q < JB; ++q) {                  // stage 1: JB independent distance evaluations
-                    double rx = spx[jb + q] - px, ry = spy[jb + q] - py;
-                    const double d2u = rx * rx + ry * ry;
-                    if (d2u < P.c_near) nb |= 1ull << ((el * NPAD + jb + q) & 63);
-                    double d2 = d2u;
-                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                    d2b[q] = (w * 64 + jb + q != i && d2 < P.c_sen) ? d2 : INFINITY;
-                }
-                nearby[w] |= nb;
+        for (int w = 0; w < NW; ++w) {
+            u64 h = cand[w];
+            while (h) {
+                const int jj = __ffsll((unsigned long long)h) - 1;
+                h &= h - 1;
+                double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                if (P.periodic) wrap_rel(rx, ry, P.w_half, P.h_half);
+                double cd = rx * rx + ry * ry; int cj = w * 64 + jj;
 #pragma unroll
-                for (int q = 0; q < JB; ++q) {                  // stage 2: ordered insertion of the candidates
-                    if (d2b[q] < INFINITY) {
-                        double cd = d2b[q]; int cj = w * 64 + jb + q;
-#pragma unroll
-                        for (int k = 0; k < kTopoMax; ++k) {
-                            const bool s = cd < nd[k];
-                            const double td = nd[k]; const int tjj = nj[k];
-                            nd[k] = s ? cd : td; nj[k] = s ? cj : tjj;
-                            cd = s ? td : cd;    cj = s ? tjj : cj;
-                        }
-                    }
+                for (int k = 0; k < kTopoMax; ++k) {
+                    const bool sw = cd < nd[k];
+                    const double td = nd[k]; const int tjj = nj[k];
+                    nd[k] = sw ? cd : td; nj[k] = sw ? cj : tjj;
+                    cd = sw ? td : cd;    cj = sw ? tjj : cj;
                 }
             }
         }
+        STAMP(13);
 #pragma unroll
         for (int w = 0; w < NW; ++w) snear[w * AG + at] = nearby[w];
 #pragma unroll
         for (int k = 0; k < kTopoMax; ++k) {                      // CPP:459-491 collision test on the NEW list
             const bool used = k < P.topo && nj[k] >= 0;
-            snei[at * kTopoMax + k] = (short)(used ? nj[k] : -1);
+            snei[at * kNeiStride + k] = (short)(used ? nj[k] : -1);
             if (used && nd[k] < P.c_avoid) collision = true;
             if (act && k < P.topo) P.nei[((size_t)e * n_a + i) * P.topo + k] = used ? nj[k] : -1;
         }
+        snei[at * kNeiStride + kTopoMax] = (short)(collision ? 1 : 0);
     }
     STAMP(3);
 
     // ---- target-cell scan over this split's words, _get_target_grid_state CPP:858-908: first-minimum
     // nearest cell, sensed-cell bits (d < d_sen), and per cell the ballot of agents with d <= r_avoid/2
     // (CPP:183-186 inverted).
-    double best = INFINITY; int bc = 0;
+    // fp32 pre-filter: a decision is taken in fp32 only when the fp32 squared distance is outside a guard band
+    // around its threshold (band = rigorous bound of the fp32 evaluation error for |coordinates| <= coord_lim);
+    // otherwise the word / the argmin is re-evaluated in fp64 exactly as the reference does.
+    const float pxf = (float)px, pyf = (float)py;
+    const bool lane_far = act && !(fabs(px) <= (double)P.coord_lim && fabs(py) <= (double)P.coord_lim);
+    const bool wave_exact = (P.force_exact != 0) || (__any(lane_far) != 0);
+    float best32 = INFINITY, second32 = INFINITY; int bc = 0;
+    const f2v pxx = {pxf, pxf}, pyy = {pyf, pyf};
+    for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
+    FENCE();
+    best32 = INFINITY; second32 = INFINITY; bc = 0;
     for (int w = 0; w < W; ++w) {
         if (!mine(w)) continue;
-        unsigned word = 0;
-        u64 mym = 0;
-        const double2 *cw = cxy_e + w * 32;
-#pragma unroll 8
-        for (int b = 0; b < 32; ++b) {
-            const double2 g = cw[b];
-            const double rx = g.x - px, ry = g.y - py;
-            const double d2 = rx * rx + ry * ry;
-            if (d2 < best) { best = d2; bc = w * 32 + b; }
-            if (d2 < P.c_sen) word |= 1u << b;
-            const u64 m = __ballot(d2 < P.c_occ);
-            if (lane == b) mym = m;
+        unsigned word = 0, rword = 0;
+        int mlo = 0, mhi = 0;                 // lanes 0..31: ballot (lo, hi halves) of cell b = lane
+        int bl = 0; const float best_in = best32;
+        u64 unc = 0;
+        const float4 *cq = reinterpret_cast<const float4 *>(cq_e + w * 64);
+        static_for<16>([&](auto prc) {
+            constexpr int pr = decltype(prc)::value;
+            const float4 q = cq[pr];                              // {xa, xb, ya, yb}
+            const f2v gx = {q.x, q.y}, gy = {q.z, q.w};
+            const f2v rx = gx - pxx, ry = gy - pyy;
+            const f2v d2v = __builtin_elementwise_fma(rx, rx, ry * ry);   // packed: two cells per instruction
+            static_for<2>([&](auto hc) {
+                constexpr int hh = decltype(hc)::value;
+                constexpr int b = 2 * pr + hh;
+                const float d2 = hh ? d2v.y : d2v.x;
+                second32 = __builtin_amdgcn_fmed3f(best32, second32, d2);
+                const bool lt = d2 < best32;                     // strict: ties keep the earlier cell
+                best32 = lt ? d2 : best32;
+                bl = lt ? b : bl;                                // word-local index: an inline constant
+                const u64 m_slo = __ballot(d2 < P.csen_lo), m_shi = __ballot(d2 < P.csen_hi);
+                const u64 m_olo = __ballot(d2 < P.cocc_lo), m_ohi = __ballot(d2 < P.cocc_hi);
+                rword = shl1_or_mask(rword, m_slo);
+                mlo = writelane_c<b>((int)(unsigned)m_olo, mlo);
+                mhi = writelane_c<b>((int)(unsigned)(m_olo >> 32), mhi);
+                unc |= (m_slo ^ m_shi) | (m_olo ^ m_ohi);
+            });
+        });
+        word = __brev(rword);
+        if (best32 < best_in) bc = w * 32 + bl;
+        u64 mym = ((u64)(unsigned)mhi << 32) | (unsigned)mlo;
+        if (unc != 0 || wave_exact) {                     // rare: redo this word exactly
+            word = 0;
+            const double2 *cw = cxy_e + w * 32;
+#pragma unroll 4
+            for (int b = 0; b < 32; ++b) {
+                const double2 g = cw[b];
+                const double rx = g.x - px, ry = g.y - py;
+                const double d2 = rx * rx + ry * ry;
+                if (d2 < P.c_sen) word |= 1u << b;
+                const u64 m = __ballot(d2 < P.c_occ);
+                if (lane == b) mym = m;
+            }
         }
         sbits[w * AG + at] = word;
         if (lane < 32) cmask[(size_t)(w * 32 + lane) * NW + aw] = mym;
     }
-    part_d[sx * AG + at] = best; part_c[sx * AG + at] = bc;
+    }
+    {   // nearest cell of this split: unambiguous in fp32 unless the runner-up is within tolerance
+        const float tol = P.min_tol_a * sqrtf(second32) + P.min_tol_b * second32 + 1e-9f;
+        const bool unc_min = act && (wave_exact || (second32 < INFINITY && (second32 - best32) <= tol));
+        if (__any(unc_min)) {
+            const float thr = unc_min ? (wave_exact ? INFINITY : best32 + tol) : -1.0f;
+            double bestd = INFINITY; int bcd = bc;
+            for (int w = 0; w < W; ++w) {
+                if (!mine(w)) continue;
+                for (int b = 0; b < 32; ++b) {
+                    const int cc = w * 32 + b;
+                    const float rx = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf, ry = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf;
+                    if (fmaf(rx, rx, ry * ry) <= thr || (wave_exact && unc_min)) {
+                        const double2 g = cxy_e[w * 32 + b];
+                        const double ex = g.x - px, ey = g.y - py;
+                        const double d2 = ex * ex + ey * ey;
+                        if (d2 < bestd) { bestd = d2; bcd = w * 32 + b; }     // ascending c: first minimum
+                    }
+                }
+            }
+            if (unc_min) bc = bcd;
+        }
+    }
+    part_c[sx * AG + at] = bc;
     __syncthreads();
-    best = INFINITY; bc = 0;
+    // merge the splits' candidates exactly: (d2 in fp64, cell index) lexicographic minimum = first minimum
+    double best = INFINITY; bc = 0;
 #pragma unroll
     for (int s = 0; s < WPE; ++s) {
-        const double d = part_d[s * AG + at]; const int c = part_c[s * AG + at];
+        const int c = part_c[s * AG + at];
+        const double2 g = cxy_e[c];
+        const double ex = g.x - px, ey = g.y - py;
+        const double d = ex * ex + ey * ey;
         if (d < best || (d == best && c < bc)) { best = d; bc = c; }
     }
     const bool in_shape = act && best < P.c_in[es];                    // CPP:889
@@ -425,8 +593,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         u64 nearby[NW];
 #pragma unroll
         for (int q = 0; q < NW; ++q) nearby[q] = in_shape ? snear[q * AG + at] : 0;
+        for (int rep = 0, reps = REPS(4); rep < reps; ++rep)
         for (int w = 0; w < W; ++w) {
             if (!mine(w)) continue;
+            FENCE();
             const unsigned word = sbits[w * AG + at];
             unsigned kw = word;
             if (in_shape) {
@@ -445,8 +615,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 #pragma unroll
                     for (int u = 0; u < 4; ++u) if (bb[u] >= 0 && occ[u]) kw &= ~(1u << bb[u]);
                 }
-                sbits[w * AG + at] = kw;
+                if (rep == reps - 1) sbits[w * AG + at] = kw;
             }
+            asm volatile("" :: "v"(kw));
             if (P.export_idx) obits[w * AG + at] = word & ~kw;
             pc[w * AG + at] = (unsigned char)__popc(kw);
         }
@@ -461,51 +632,83 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     for (int w = 0; w < W; ++w) n_kept += pc[w * AG + at];
     const int G = P.g_max;
     const int n_sel = n_kept > G ? G : n_kept;
-    {
+    // (1) which RANKS of the kept list survive the cap?  rank(s) = round(s * (n-1)/(G-1)), s = 0..G-1 (CPP:241-245),
+    // evaluated in a uniform slot loop (split sx takes slots sx, sx+WPE, ...) and OR-ed into a per-lane bit set.
+    // With G-1 odd the value s(n-1)/(G-1) is never within 1/(2(G-1)) of a half-integer, so the reference's fp64
+    // round() equals the integer floor((2 s (n-1) + (G-1)) / (2 (G-1))) exactly; for even G-1 (ties possible) the
+    // reference's fp64 expression is evaluated as is.
+    unsigned *rsel = reinterpret_cast<unsigned *>(smem + P.off_cmask);      // [W+1][AG] (aliases cmask: consumed)
+    for (int w = sx; w <= W; w += WPE) rsel[w * AG + at] = 0;
+    __syncthreads();
+    for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
+        FENCE();
         const bool sub = n_kept > G;
+        const unsigned nm1 = (unsigned)(n_kept - 1);
         const double step = sub ? (double)(n_kept - 1) / (G - 1) : 0.0;
-        int s = 0, target = 0, prefix = 0;
+        for (int q = sx; q < n_sel; q += WPE) {
+            unsigned r = (unsigned)q;
+            if (sub) {
+                if (P.cap_int) {
+                    const unsigned x = 2u * (unsigned)q * nm1 + (unsigned)(G - 1);
+                    const unsigned hq = __umulhi(x, P.cap_magic);
+                    r = (((x - hq) >> 1) + hq) >> P.cap_shift;                 // x / (2 (G-1)), Granlund-Montgomery
+                } else {
+                    r = (unsigned)(int)round(q * step);
+                }
+            }
+            atomicOr(&rsel[(r >> 5) * AG + at], 1u << (r & 31));
+        }
+    }
+    __syncthreads();
+    // (2) emit: every split walks the words in order to carry the running rank / slot counters; it writes the
+    // slots of its own words.
+    {
         short *row = sidx + (size_t)at * P.g_stride;
+        int prefix = 0, sbase = 0;
         for (int w = 0; w < W; ++w) {
             const int cnt = pc[w * AG + at];
+            unsigned bits = 0;
+            if (cnt) {
+                const int wi = prefix >> 5, sh = prefix & 31;
+                const u64 two = ((u64)rsel[(wi + 1) * AG + at] << 32) | rsel[wi * AG + at];
+                bits = (unsigned)(two >> sh) & (cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u));
+            }
             if (mine(w)) {
-                unsigned it = sbits[w * AG + at];
-                int k = prefix;
+                unsigned it = sbits[w * AG + at], sel = bits;
+                int s = sbase;
                 while (it) {
                     const int b = __ffs(it) - 1;
                     it &= it - 1;
-                    const int c = w * 32 + b;
-                    bool sel;
-                    if (sub) {
-                        while (target < k && s < G) { ++s; target = (int)round(s * step); }   // CPP:245
-                        sel = (s < G) && (target == k);
-                    } else { s = k; sel = true; }
-                    if (sel) row[s] = (short)c;
-                    ++k;
+                    if (sel & 1u) { row[s] = (short)(w * 32 + b); ++s; }
+                    sel >>= 1;
                 }
             }
+            sbase += __popc(bits);
             prefix += cnt;
         }
         for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
     }
     __syncthreads();
-    // exploration-reward sums over the capped list (CPP:494-551): split sx takes slots sx, sx+WPE, ...;
-    // independent iterations (unrolled) instead of a serial bit walk.
+    // exploration-reward sums over the capped list (CPP:494-551), fp32 fast path: split sx takes slots
+    // sx, sx+WPE, ...; independent iterations (unrolled).  The fp32 result only DECIDES when |v| is outside a
+    // guard band around the 0.05 threshold; inside it the sums are redone in fp64 below.
     {
-        const double inv_dsen = 1.0 / P.d_sen;
-        double num0 = 0.0, num1 = 0.0, den = 0.0;
+        const float inv_dsen2 = (float)(1.0 / (P.d_sen * P.d_sen));
+        float num0 = 0.0f, num1 = 0.0f, den = 0.0f;
         const short *row = sidx + (size_t)at * P.g_stride;
         const int lim = in_shape ? n_sel : 0;
+        for (int rep = 0, reps = REPS(6); rep < reps; ++rep) {
+        FENCE();
+        num0 = 0.0f; num1 = 0.0f; den = 0.0f;
 #pragma unroll 4
         for (int q = sx; q < G; q += WPE) {
             if (q < lim) {
-                const double2 g = cxy_e[row[q]];
-                const double x = g.x - px, y = g.y - py;
-                const double z = sqrt(x * x + y * y);
-                // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
-                const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
-                num0 += psi * x; num1 += psi * y; den += psi;
+                const int cc = row[q];
+                const float x = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf, y = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf;
+                const float psi = psi_u_f32(fmaf(x, x, y * y) * inv_dsen2);
+                num0 = fmaf(psi, x, num0); num1 = fmaf(psi, y, num1); den += psi;
             }
+        }
         }
         rsum[(sx * 3 + 0) * AG + at] = num0; rsum[(sx * 3 + 1) * AG + at] = num1; rsum[(sx * 3 + 2) * AG + at] = den;
     }
@@ -513,19 +716,37 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     STAMP(6);
 
     if (sx == 0) {
-        double num0 = 0.0, num1 = 0.0, den = 0.0;
+        float n0 = 0.0f, n1 = 0.0f, dn = 0.0f;
 #pragma unroll
         for (int s = 0; s < WPE; ++s) {
-            num0 += rsum[(s * 3 + 0) * AG + at]; num1 += rsum[(s * 3 + 1) * AG + at]; den += rsum[(s * 3 + 2) * AG + at];
+            n0 += rsum[(s * 3 + 0) * AG + at]; n1 += rsum[(s * 3 + 1) * AG + at]; dn += rsum[(s * 3 + 2) * AG + at];
         }
         bool uniform = false;
-        if (in_shape && n_sel > 0) {
-            if (den == 0) den = 1E-8;
-            const double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;
-            uniform = sqrt(v0 * v0 + v1 * v1) < 0.05;
+        const bool has = in_shape && n_sel > 0;
+        const float v0f = n0 / dn, v1f = n1 / dn;
+        const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
+        uniform = has && vf < 0.05f;
+        const bool unsure = has && (P.force_exact || !(dn > 1e-3f) || !(fabsf(vf - 0.05f) > P.rew_guard));
+        if (__any(unsure)) {
+            if (unsure) {      // exact: fp64, slot order (CPP:529-549)
+                const double inv_dsen = 1.0 / P.d_sen;
+                const short *row = sidx + (size_t)at * P.g_stride;
+                double num0 = 0.0, num1 = 0.0, den = 0.0;
+                for (int q = 0; q < n_sel; ++q) {
+                    const double2 g = cxy_e[row[q]];
+                    const double x = g.x - px, y = g.y - py;
+                    const double z = sqrt(x * x + y * y);
+                    // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
+                    const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
+                    num0 += psi * x; num1 += psi * y; den += psi;
+                }
+                if (den == 0) den = 1E-8;
+                const double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;
+                uniform = sqrt(v0 * v0 + v1 * v1) < 0.05;
+            }
         }
         if (act) {
-            if (reward != nullptr) reward[(size_t)e * n_a + i] = (in_shape && !collision && uniform) ? 1.0f : 0.0f;   // CPP:554-556
+            if (reward != nullptr) reward[(size_t)e * n_a + i] = (in_shape && !(snei[at * kNeiStride + kTopoMax] != 0) && uniform) ? 1.0f : 0.0f;   // CPP:554-556
             if (done != nullptr) done[(size_t)e * n_a + i] = 0;                                                         // ENV:480-482
         }
         if (P.export_idx && act) {
@@ -554,60 +775,83 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
 
-    // ---- observation rows, CPP:102-137,274-306: streamed out as (value, value) pairs, consecutive lanes
-    // -> consecutive addresses; the rows of this workgroup's environments are contiguous in HBM.
+    // ---- observation rows, CPP:102-137,274-306, streamed out as (value, value) pairs with consecutive lanes
+    // on consecutive addresses (the rows of this workgroup's environments are contiguous in HBM).  Two passes with
+    // wave-uniform control flow: the 2*(self+topo)+2 head pairs of every row, then the G sensed-cell pairs.
     if (obs != nullptr) {
         const int PPR = P.obs_dim >> 1;                  // pairs per row
-        const int base_pairs = 2 * (P.with_self + P.topo);
+        const int HP = 2 * (P.with_self + P.topo) + 2;   // head pairs: agent block + target pos/vel
         const int envs_here = (P.n_env - blockIdx.x * EPB) < EPB ? (P.n_env - blockIdx.x * EPB) : EPB;
-        const int total = envs_here * n_a * PPR;
+        const int rows = envs_here * n_a;
         OT2 *out = reinterpret_cast<OT2 *>(obs) + (size_t)blockIdx.x * EPB * n_a * PPR;
-        const int dr = T / PPR, dq = T % PPR;
-        int r = tid / PPR, q = tid % PPR;
-#pragma unroll 2
-        for (int L = tid; L < total; L += T) {
-            const int elr = EPB > 1 ? r / n_a : 0;
-            const int ir = r - elr * n_a;
-            const int tr = elr * NPAD + ir;
-            const double qx = sp[tr], qy = sp[AG + tr], ux = sp[2 * AG + tr], uy = sp[3 * AG + tr];
-            const int ncf = sncf[tr];
-            const double2 *cx = cxy + (size_t)elr * P.cxy_stride;
-            double a = 0.0, b = 0.0;
-            if (q < base_pairs) {
+        for (int rep = 0, reps = REPS(7); rep < reps; ++rep) {
+            FENCE();
+            const int total = rows * HP;
+            const int dr = T / HP, dq = T % HP;
+            int r = tid / HP, q = tid % HP;
+            for (int L = tid; L < total; L += T) {
+                const int elr = EPB > 1 ? r / n_a : 0;
+                const int tr = elr * NPAD + (r - elr * n_a);
+                const double qx = sp[tr], qy = sp[AG + tr], ux = sp[2 * AG + tr], uy = sp[3 * AG + tr];
                 const int blk = q >> 1, half = q & 1;
-                if (P.with_self && blk == 0) {                          // CPP:103-113
-                    a = half ? ux : qx; b = half ? uy : qy;
-                } else {
-                    const int j = snei[tr * kTopoMax + (blk - P.with_self)];
-                    if (j >= 0) {
-                        const int tj = elr * NPAD + j;
-                        if (half) { a = sp[2 * AG + tj] - ux; b = sp[3 * AG + tj] - uy; }     // CPP:80-81
-                        else {
-                            a = sp[tj] - qx; b = sp[AG + tj] - qy;                           // CPP:79
-                            if (P.periodic) wrap_rel(a, b, P.w_half, P.h_half);
+                double a = 0.0, b = 0.0;
+                if (q < HP - 2) {
+                    if (P.with_self && blk == 0) {                      // CPP:103-113
+                        a = half ? ux : qx; b = half ? uy : qy;
+                    } else {
+                        const int j = snei[tr * kNeiStride + (blk - P.with_self)];
+                        if (j >= 0) {
+                            const int tj = elr * NPAD + j;
+                            if (half) { a = sp[2 * AG + tj] - ux; b = sp[3 * AG + tj] - uy; }     // CPP:80-81
+                            else {
+                                a = sp[tj] - qx; b = sp[AG + tj] - qy;                           // CPP:79
+                                if (P.periodic) wrap_rel(a, b, P.w_half, P.h_half);
+                            }
                         }
                     }
+                } else {
+                    const int ncf = sncf[tr];
+                    if (half == 0) {                                    // CPP:136
+                        if (ncf >> 30) { a = qx - qx; b = qy - qy; }
+                        else { const double2 g = cxy[(size_t)elr * P.cxy_stride + (ncf & 0xFFFF)]; a = g.x - qx; b = g.y - qy; }
+                    } else {                                            // CPP:137
+                        if (ncf >> 30) { a = ux - ux; b = uy - uy; }
+                        else { a = 0.0 - ux; b = 0.0 - uy; }
+                    }
                 }
-            } else if (q == base_pairs) {                               // CPP:136
-                if (ncf >> 30) { a = qx - qx; b = qy - qy; }
-                else { const double2 g = cx[ncf & 0xFFFF]; a = g.x - qx; b = g.y - qy; }
-            } else if (q == base_pairs + 1) {                           // CPP:137
-                if (ncf >> 30) { a = ux - ux; b = uy - uy; }
-                else { a = 0.0 - ux; b = 0.0 - uy; }
-            } else {                                                    // CPP:274-291
-                const int c = sidx[(size_t)tr * P.g_stride + (q - base_pairs - 2)];
-                if (c >= 0) { const double2 g = cx[c]; a = g.x - qx; b = g.y - qy; }
+                OT2 o; o.x = (OT)a; o.y = (OT)b;
+                out[(size_t)r * PPR + q] = o;
+                q += dq; r += dr;
+                if (q >= HP) { q -= HP; ++r; }
             }
-            OT2 o; o.x = (OT)a; o.y = (OT)b;
-            out[L] = o;
-            q += dq; r += dr;
-            if (q >= PPR) { q -= PPR; ++r; }
+        }
+        for (int rep = 0, reps = REPS(8); rep < reps; ++rep) {
+            FENCE();
+            const int Gp = P.g_max;
+            const int total = rows * Gp;
+            const int dr = T / Gp, dq = T % Gp;
+            int r = tid / Gp, q = tid % Gp;
+#pragma unroll 2
+            for (int L = tid; L < total; L += T) {                      // CPP:274-291
+                const int elr = EPB > 1 ? r / n_a : 0;
+                const int tr = elr * NPAD + (r - elr * n_a);
+                const int c = sidx[(size_t)tr * P.g_stride + q];
+                double a = 0.0, b = 0.0;
+                if (c >= 0) {
+                    const double2 g = cxy[(size_t)elr * P.cxy_stride + c];
+                    a = g.x - sp[tr]; b = g.y - sp[AG + tr];
+                }
+                OT2 o; o.x = (OT)a; o.y = (OT)b;
+                out[(size_t)r * PPR + HP + q] = o;
+                q += dq; r += dr;
+                if (q >= Gp) { q -= Gp; ++r; }
+            }
         }
     }
     STAMP(7);
 #ifdef SWARM_STAMPS
     if (P.stamps != nullptr && tid == 0)
-        for (int k = 0; k < 8; ++k) P.stamps[(size_t)blockIdx.x * 8 + k] = stamp_t[k];
+        for (int k = 0; k < 16; ++k) P.stamps[(size_t)blockIdx.x * 16 + k] = stamp_t[k];
 #endif
 }
 
@@ -695,10 +939,12 @@ void layout_t(KP &k)
     auto max2 = [](size_t a, size_t b) { return a > b ? a : b; };
     k.off_cxy = take((size_t)EPB * k.cxy_stride * 16);
     k.off_sp = take((size_t)4 * AG * 8);
-    k.off_cmask = take(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 8));      // cmask | rsum
+    k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
+    k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);
+    k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)k.ngw * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * AG * 12));          // sidx | part_d, part_c
-    k.off_snei = take((size_t)AG * kTopoMax * 2);
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * AG * 4));           // sidx | part_c
+    k.off_snei = take((size_t)AG * kNeiStride * 2);
     k.off_sncf = take((size_t)AG * 4);
     k.off_snear = take((size_t)NW * AG * 8);
     k.off_pc = take((size_t)k.ngw * AG);
@@ -834,6 +1080,35 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     k.c_occ = cut_le(k.r_avoid / 2.0);                    // !(norm > r_avoid/2)       CPP:185
     k.c_avoid = cut_lt(k.r_avoid);                        // r_avoid > norm            CPP:482
     k.c_ball = cut_lt(k.size2);                           // d_center - sizes < 0      ENV:450-451
+    {   // fp32 pre-filter bands.  With |coordinates| <= S, a float-converted coordinate is off by <= 2^-24 S and
+        // their float difference by another 2^-24 S at most: dr = 4 * 2^-24 * S bounds each component of the fp32
+        // relative position (1.33x margin).  Then |d2_32 - d2_64| <= 2 sqrt(2) |r| dr + O(2^-23 d2) <= 3 sqrt(d2) dr + 2^-21 d2.
+        double S = 0.0;
+        for (int q = 0; q < 4; ++q) S = std::fmax(S, std::fabs(cfg->boundary[q]));
+        S = 1.5 * S + 1.0;
+        const double dr = 4.0 * std::ldexp(1.0, -24) * S;
+        auto band = [&](double c) { return 3.0 * std::sqrt(c) * dr + std::ldexp(1.0, -21) * c + 1e-12; };
+        auto f_below = [](double v) { float f = (float)v; while ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; };
+        auto f_above = [](double v) { float f = (float)v; while ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
+        k.csen_lo = f_below(k.c_sen - band(k.c_sen)); k.csen_hi = f_above(k.c_sen + band(k.c_sen));
+        k.cocc_lo = f_below(k.c_occ - band(k.c_occ)); k.cocc_hi = f_above(k.c_occ + band(k.c_occ));
+        k.coord_lim = (float)S;
+        k.min_tol_a = (float)(2.0 * 3.0 * dr); k.min_tol_b = (float)(2.0 * std::ldexp(1.0, -21));
+        k.rew_guard = 1.0e-4f;          // fp32 |v| error is < 1e-5 for <= 4096 list entries
+        k.force_exact = (cfg->debug_flags & 1) ? 1 : 0;
+        {   // unsigned division by D = 2 (G-1) (Granlund-Montgomery round-up method, exact for every 32-bit x)
+            const unsigned D = 2u * (unsigned)(k.g_max - 1);
+            int l = 0;
+            while ((1ull << l) < D) ++l;
+            k.cap_magic = (unsigned)((((1ull << l) - D) << 32) / D + 1);
+            k.cap_shift = l - 1;
+            // numerators stay below 2^32: 2 (G-1) (n_cells_max-1) + (G-1)
+            const unsigned long long xmax = 2ull * (k.g_max - 1) * (unsigned long long)k.ng_max + k.g_max;
+            k.cap_int = (((k.g_max - 1) & 1) == 1 && xmax < (1ull << 32) && l >= 1) ? 1 : 0;
+        }
+        k.dbg_phase = (cfg->debug_flags >> 8) & 0xF;
+        k.dbg_extra = (cfg->debug_flags >> 12) & 0xF;
+    }
     layout(k, h->npad);
 
     DeviceGuard g(dev);
@@ -1039,11 +1314,11 @@ int swarm_debug_stamps(swarm_env_t *h, const void *action, int action_dtype, voi
     const int grid = (h->cfg.n_env + epb - 1) / epb;   // same for every Geo<NPAD>
     if (grid > max_blocks) return -1;
     long long *d = nullptr;
-    if (hipMalloc((void **)&d, (size_t)grid * 8 * sizeof(long long)) != hipSuccess) return -1;
+    if (hipMalloc((void **)&d, (size_t)grid * 16 * sizeof(long long)) != hipSuccess) return -1;
     h->kp.stamps = d;
     int rc = launch(h, true, action, action_dtype == SWARM_F64, obs, reward, done, a_prior);
     h->kp.stamps = nullptr;
-    if (rc == SWARM_OK && hipMemcpy(out, d, (size_t)grid * 8 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+    if (rc == SWARM_OK && hipMemcpy(out, d, (size_t)grid * 16 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
     (void)hipFree(d);
     return rc == SWARM_OK ? grid : -1;
 }

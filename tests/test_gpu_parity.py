@@ -159,7 +159,8 @@ def test_small_caps(oracle, shapes):
     cases = [make_case(rng, shapes, n_a, 1) for _ in range(n_env)]
     ng_max = max(c[2].shape[1] for c in cases)
     cells, n_g = _pad_cells([c[2] for c in cases], ng_max)
-    for topo, g_max, occ_max in ((3, 10, 7), (6, 80, 20), (1, 6, 200)):
+    # (G-1 odd -> integer cap arithmetic; G-1 even -> the reference's fp64 round(), ties possible)
+    for topo, g_max, occ_max in ((3, 10, 7), (6, 80, 20), (1, 6, 200), (2, 5, 9), (6, 81, 33), (4, 21, 11)):
         sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=ng_max, r_avoid=ra, topo=topo, g_max=g_max,
                     occ_max=occ_max, obs_dtype=torch.float64)
         sb.set_cells(cells, n_g, [c[3] for c in cases])
@@ -229,3 +230,120 @@ def test_error_behaviour(shapes):
     with pytest.raises(SwarmError):                  # wrong action shape
         sb.step(torch.zeros((2, 7, 2), device=sb.device))
     sb.close()
+
+
+def _adversarial_case(rng, shapes, n_a, ra, d_sen=0.4):
+    """Agents placed (almost) exactly ON the decision thresholds the fp32 pre-filter has to resolve:
+    distance to a cell ~ d_sen and ~ r_avoid/2 (sensed / occupied bits), the midpoint between two cells
+    (nearest-cell ties), the in-shape radius, and agent pairs ~ d_sen, r_avoid and 0.07 apart."""
+    p, dp, g, l_cell = make_case(rng, shapes, n_a, 1)
+    eps = [0.0, 1e-16, -1e-16, 1e-13, -1e-13, 1e-10, -1e-10, 1e-8, -1e-8, 3e-7, -3e-7, 2e-6, -2e-6]
+    k = 0
+    for i in range(n_a):
+        c = int(rng.integers(0, g.shape[1]))
+        th = rng.uniform(0, 2 * np.pi)
+        u = np.array([np.cos(th), np.sin(th)])
+        mode = i % 6
+        e = eps[k % len(eps)]; k += 1
+        if mode == 0:
+            p[:, i] = g[:, c] + u * d_sen * (1 + e)
+        elif mode == 1:
+            p[:, i] = g[:, c] + u * (ra / 2) * (1 + e)
+        elif mode == 2:
+            c2 = (c + 1) % g.shape[1]
+            mid = 0.5 * (g[:, c] + g[:, c2]); d = g[:, c2] - g[:, c]
+            p[:, i] = mid + d * e + np.array([-d[1], d[0]]) * rng.uniform(-0.3, 0.3)
+        elif mode == 3:
+            p[:, i] = g[:, c] + u * (np.sqrt(2) * l_cell / 2) * (1 + e)
+        elif mode == 4 and i > 0:
+            p[:, i] = p[:, i - 1] + u * [d_sen, ra, 0.07, d_sen + ra / 2][k % 4] * (1 + e)
+    return np.ascontiguousarray(p), dp, g, l_cell
+
+
+@pytest.mark.parametrize("n_a,n_env,force", [(64, 24, 0), (64, 8, 1), (32, 16, 0), (8, 16, 0), (256, 3, 0), (100, 4, 1)])
+def test_threshold_adversarial_inputs(oracle, shapes, n_a, n_env, force):
+    """The fp32 pre-filter must hand every borderline decision to the exact fp64 path: masks, flags and the
+    step stay bit-identical to the oracle on inputs constructed to sit on the thresholds.  force=1 runs the
+    same inputs with every exact fallback forced (debug flag) -- both must agree with the oracle."""
+    from marl_llm_amd.shapes import r_avoid_for
+    rng = np.random.default_rng(4242 + n_a + force)
+    ra = r_avoid_for(n_a, shapes)
+    cases = [_adversarial_case(rng, shapes, n_a, ra) for _ in range(n_env)]
+    ng_max = max(c[2].shape[1] for c in cases)
+    cells, n_g = _pad_cells([c[2] for c in cases], ng_max)
+    sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=ng_max, r_avoid=ra, obs_dtype=torch.float64, debug_flags=force)
+    sb.set_cells(cells, n_g, [c[3] for c in cases])
+    sb.set_state(np.stack([c[0] for c in cases]), np.stack([c[1] for c in cases]))
+    obs0 = sb.observe().cpu().numpy()
+    idx = sb.indices()
+    nei = []
+    for e, (pe, dpe, g, l_cell) in enumerate(cases):
+        o = oracle.get_observation(pe, dpe, g, l_cell, ra)
+        for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+            assert np.array_equal(idx[k][e].cpu().numpy(), o[k]), (e, k)
+        assert np.array_equal(obs0[e], _to_rows(o["obs"])), e
+        nei.append(o["neighbor_index"])
+    act = np.zeros((n_env, n_a, 2), np.float32)          # zero action: the agents stay near the thresholds
+    obs, rew, done, pri = sb.step(torch.from_numpy(act).to(sb.device))
+    idx = sb.indices()
+    pg, dpg = [x.cpu().numpy() for x in sb.get_state()]
+    for e, (pe, dpe, g, l_cell) in enumerate(cases):
+        s = oracle.step(pe, dpe, np.ascontiguousarray(act[e].T), g, nei[e], l_cell, ra)
+        assert np.array_equal(pg[e], s["p"]) and np.array_equal(dpg[e], s["dp"])
+        assert np.array_equal(obs[e].cpu().numpy(), _to_rows(s["obs"]))
+        assert np.array_equal(rew[e].cpu().numpy().astype(np.float64), s["reward"][0])
+        for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+            assert np.array_equal(idx[k][e].cpu().numpy(), s[k]), (e, k)
+    sb.close()
+
+
+def test_forced_exact_paths_equal_fast_paths(shapes):
+    """Whole-batch consistency: fast (fp32 pre-filter) and forced-exact runs give identical outputs over
+    several free-running steps at a BASELINE-sized agent count."""
+    from marl_llm_amd.shapes import r_avoid_for
+    from marl_llm_amd.synth import synthetic_batch
+    n_a, n_env = 64, 512
+    ra = r_avoid_for(n_a, shapes)
+    sy = synthetic_batch(n_env, n_a, shapes, seed=11, assembled_fraction=0.6)
+    outs = []
+    for force in (0, 1):
+        sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra, debug_flags=force)
+        sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"]); sb.set_state(sy["p"], sy["dp"]); sb.observe()
+        act = torch.zeros((n_env, n_a, 2), device=sb.device)
+        rews = []
+        for t in range(12):
+            obs, rew, done, act = sb.step(act)
+            rews.append(rew.clone())
+        p, dp = sb.get_state()
+        idx = sb.indices()
+        outs.append((obs.clone(), torch.stack(rews), p, dp, idx["sensed_index"], idx["occupied_index"], idx["in_flags"]))
+        sb.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert outs[0][1].sum().item() > 0          # some agents do earn the reward in this workload
+
+
+def test_diagnostic_repeat_hooks_do_not_change_results(shapes):
+    """tools/ablate.py relies on every phase being idempotent: running any phase extra times (debug hook) must
+    leave every output bit-identical."""
+    from marl_llm_amd.shapes import r_avoid_for
+    from marl_llm_amd.synth import synthetic_batch
+    n_a, n_env = 64, 96
+    ra = r_avoid_for(n_a, shapes)
+    sy = synthetic_batch(n_env, n_a, shapes, seed=5, assembled_fraction=0.6)
+    ref = None
+    for flags in [0] + [(k << 8) | (2 << 12) for k in range(1, 9)]:
+        sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra, debug_flags=flags)
+        sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"]); sb.set_state(sy["p"], sy["dp"]); sb.observe()
+        act = torch.zeros((n_env, n_a, 2), device=sb.device)
+        for t in range(4):
+            obs, rew, done, act = sb.step(act)
+        p, dp = sb.get_state()
+        idx = sb.indices()
+        out = (obs.clone(), rew.clone(), act.clone(), p, dp, idx["sensed_index"], idx["occupied_index"], idx["neighbor_index"])
+        sb.close()
+        if ref is None:
+            ref = out
+        else:
+            for a, b in zip(ref, out):
+                assert torch.equal(a, b), flags

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Diagnostic: time the step kernel with one phase run EXTRA times (debug_flags bits 8..11 = phase, 12..15 = extra
+repeats; the phases are idempotent, so outputs do not change).  The extra time / instructions per repeat are that
+phase's cost.  Under `rocprofv3 --pmc SQ_INSTS_VALU` + tools/ablate_pmc.py this gives exact per-phase VALU counts."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from marl_llm_amd.batched import SwarmBatch
+from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
+from marl_llm_amd.synth import synthetic_batch
+
+NAMES = ["forces+prior+integrate", "neighbour search", "cell scan", "occupied filter", "list emit", "reward sums",
+         "obs head pairs", "obs sensed pairs"]
+
+
+def run(skip, n_a, E, sy, ra, state, steps=int(os.environ.get('ABLATE_STEPS', '60'))):
+    sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra, debug_flags=skip)
+    sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"])
+    sb.set_state(state[0], state[1]); sb.observe()
+    act = torch.zeros((E, n_a, 2), device=sb.device)
+    for _ in range(5):
+        sb.step(act)
+    sb.set_state(state[0], state[1]); sb.observe()
+    sb.timer_start()
+    for _ in range(steps):
+        sb.step(act)               # zero action: the swarm stays where it is -> same work every step
+    ms = sb.timer_stop() / steps
+    sb.close()
+    return ms
+
+
+def main():
+    n_a = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    E = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    shapes = synthetic_shape_set()
+    ra = r_avoid_for(n_a, shapes)
+    sy = synthetic_batch(E, n_a, shapes, seed=226)
+    sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra)
+    sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"]); sb.set_state(sy["p"], sy["dp"]); sb.observe()
+    act = torch.zeros((E, n_a, 2), device=sb.device)
+    for _ in range(100):
+        act = sb.step(act)[3]
+    state = [x.cpu().numpy() for x in sb.get_state()]
+    sb.close()
+    extra = 2
+    base = run(0, n_a, E, sy, ra, state)
+    print(f"{n_a} agents x {E} envs, assembled, zero action: full kernel {base * 1e3:.1f} us")
+    tot = 0.0
+    for k, nm in enumerate(NAMES):
+        ms = run(((k + 1) << 8) | (extra << 12), n_a, E, sy, ra, state)
+        d = (ms - base) / extra
+        tot += d
+        print(f"  {nm:24s} +{extra} repeats: {ms * 1e3:8.1f} us   (phase ~ {d * 1e3:6.1f} us, {100 * d / base:5.1f} %)")
+    print(f"  sum of phases {tot * 1e3:.1f} us; remainder (loads, staging, barriers, merges) {(base - tot) * 1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

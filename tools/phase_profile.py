@@ -36,18 +36,25 @@ def main():
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int]
     grid_max = E
-    out = np.zeros((grid_max, 8), np.int64)
+    out = np.zeros((grid_max, 16), np.int64)
     obs, rew, done, pri = sb._obs[0], sb._rew[0], sb._done, sb._pri[0]
     g = fn(sb.handle, act.data_ptr(), 0, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), pri.data_ptr(),
            out.ctypes.data_as(ctypes.c_void_p), grid_max)
     assert g > 0, g
     t = out[:g].astype(np.float64)
+    fine = t[:, 8:14]
+    t = t[:, :8]
     d = np.diff(t, axis=1)
     tot = t[:, 7] - t[:, 0]
     print(f"{n_a} agents x {E} envs: {g} workgroups, mean cycles/workgroup {tot.mean():.0f} "
           f"(min {tot.min():.0f}, max {tot.max():.0f}); kernel span {(t[:, 7].max() - t[:, 0].min()):.0f} cycles")
     for k, name in enumerate(PHASES):
         print(f"  {name:26s} {d[:, k].mean():10.0f} cycles  {100 * d[:, k].mean() / tot.mean():5.1f} %")
+    t1 = t[:, 1]
+    names = ["contact loop done", "walls done", "prior done", "integration done", "barrier B passed", "neighbour loops done"]
+    print("  split-0 fine stamps (cycles since 'load' end):")
+    for k, nm in enumerate(names):
+        print(f"    {nm:24s} {(fine[:, k] - t1).mean():10.0f}")
 
 
 if __name__ == "__main__":
