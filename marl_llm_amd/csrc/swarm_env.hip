@@ -63,7 +63,7 @@ struct KP {
     unsigned cap_magic; int cap_shift;
     int dbg_phase, dbg_extra;  // diagnostics only (tools/ablate.py): run phase dbg_phase dbg_extra EXTRA times; the
                                // phases are idempotent, so results are unchanged and the extra cost is the phase's cost
-    int off_cxyf;
+    int off_cxyf, off_partc;
     double d_sen, r_avoid, size_a, size2, k_ball, k_wall, c_wall, vel_max, dt;
     double bx0, by1, bx2, by3, w_half, h_half;
     double *p, *dp;
@@ -195,7 +195,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     typedef typename Pair<OT>::type OT2;
 
     extern __shared__ __align__(16) unsigned char smem[];
-    double2 *cxy = reinterpret_cast<double2 *>(smem + P.off_cxy);
     float *cxq = reinterpret_cast<float *>(smem + P.off_cxyf);          // fp32 cells, per PAIR {xa, xb, ya, yb} (pre-filter)
     double *sp = reinterpret_cast<double *>(smem + P.off_sp);            // [4][AG]: px, py, vx, vy
     u64 *cmask = reinterpret_cast<u64 *>(smem + P.off_cmask);            // [cell][NW]
@@ -203,7 +202,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     unsigned *sbits = reinterpret_cast<unsigned *>(smem + P.off_sbits);  // [word][AG]
     unsigned *obits = reinterpret_cast<unsigned *>(smem + P.off_obits);  // [word][AG] (export launches only)
     short *sidx = reinterpret_cast<short *>(smem + P.off_sidx);          // [AG][g_stride]
-    int *part_c = reinterpret_cast<int *>(smem + P.off_sidx);            // [WPE][AG]     (aliases sidx, earlier phase)
+    int *part_c = reinterpret_cast<int *>(smem + P.off_partc);           // [WPE][AG] per-split nearest-cell candidates
+    u64 *pm = reinterpret_cast<u64 *>(smem + P.off_sidx);                // [WPE][2][AG] partial pair masks (aliases sidx, earlier phase)
+    unsigned *owords = reinterpret_cast<unsigned *>(smem + P.off_cmask); // [word][AG] occupied bits (NW == 1; aliases cmask)
     short *snei = reinterpret_cast<short *>(smem + P.off_snei);          // [AG][kTopoMax]
     int *sncf = reinterpret_cast<int *>(smem + P.off_sncf);              // [AG]: nearest cell | in_flag<<30
     u64 *snear = reinterpret_cast<u64 *>(smem + P.off_snear);            // [NW][AG] nearby-agent masks
@@ -246,7 +247,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int o = (w - w0) % (WPE - 1);            // o-th of the non-B splits
         return sx == (o < SB ? o : o + 1);
     };
-    double2 *cxy_e = cxy + (size_t)el * P.cxy_stride;
+    // exact (fp64) cell coordinates are read from global memory where they are needed (prior target, nearest-cell
+    // merge, observation values, the rare exact fallbacks); the env's 8.7 KB of cells stay L1/L2 resident.
+    const double *gxe = P.cells + (size_t)es * 2 * P.ng_max, *gye = gxe + P.ng_max;
+    auto cell64 = [&](int c) -> double2 { double2 g; g.x = c < ng ? gxe[c] : kSentinel; g.y = c < ng ? gye[c] : kSentinel; return g; };
     const float *cq_e = cxq + (size_t)el * P.cxq_stride;
 
     // ---- issue every global load of the step up front (their latency overlaps the cell staging)
@@ -273,7 +277,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     // ---- stage the target cells (ENV: grid_center (2, n_g)) in LDS: (x, y) f64 pairs and an fp32 copy laid out
     // per pair of cells {xa, xb, ya, yb} for packed arithmetic; pad with a sentinel (fp32: +inf)
+    for (int rep = 0, reps = REPS(9); rep < reps; ++rep)
     for (int k = 0; k < EPB; ++k) {
+        FENCE();
         const int ek0 = blockIdx.x * EPB + k;
         const int ek = ek0 < P.n_env ? ek0 : P.n_env - 1;
         const int ngk = P.n_g[ek];
@@ -283,7 +289,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             double2 g;
             g.x = c < ngk ? gx[c] : kSentinel;
             g.y = c < ngk ? gy[c] : kSentinel;
-            cxy[(size_t)k * P.cxy_stride + c] = g;
             float *q = cxq + (size_t)k * P.cxq_stride + (c >> 1) * 4 + (c & 1);
             q[0] = (float)g.x; q[2] = (float)g.y;
         }
@@ -303,7 +308,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             if (P.with_prior && act && a_prior != nullptr) {
                 double tx, ty;
                 if (inf) { tx = px - px; ty = py - py; }
-                else { const double2 g = cxy_e[ncell]; tx = g.x - px; ty = g.y - py; }
+                else { const double2 g = cell64(ncell); tx = g.x - px; ty = g.y - py; }
                 double qx = 0.0, qy = 0.0;
                 const double dt_ = sqrt(tx * tx + ty * ty);
                 if (dt_ > 0) { qx += 2.0 * tx / dt_; qy += 2.0 * ty / dt_; }
@@ -417,34 +422,65 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at];
     STAMP(2);
 
-    // ---- neighbour search (split 0), CPP:77-100 + _get_focused CPP:628-698: the topo nearest agents with
-    // norm < d_sen (self removed), ascending.  Also the "nearby" agent mask of the occupied-cell filter
-    // (CPP:152-164: un-wrapped distance < d_sen + r_avoid/2, self included).
-    if (sx == SB) for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
+    // ---- pairwise masks + neighbour search, CPP:77-100 + _get_focused CPP:628-698: the topo nearest agents with
+    // norm < d_sen (self removed), ascending; and the "nearby" agent mask of the occupied-cell filter
+    // (CPP:152-164: un-wrapped distance < d_sen + r_avoid/2, self included).  For N <= 64 the branch-free mask
+    // pass is dealt over all splits (a quarter of the agents j each) and OR-combined through LDS; the ordered
+    // insertion of the (few) candidates runs on split B.
+    constexpr int JN = NPAD < 64 ? NPAD : 64;                   // lanes >= n_a hold NaN positions: never candidates
+    const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
+    u64 nearby1 = 0, cand1 = 0;                                  // NW == 1: this lane's complete masks
+    if constexpr (NW == 1) {
+        constexpr int JQ = (JN + WPE - 1) / WPE;
+        u64 nb = 0, cd = 0;
+        for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
+            FENCE();
+            nb = 0; cd = 0;
+#pragma unroll
+            for (int q = 0; q < JQ; ++q) {
+                const int jj = sx * JQ + q;
+                if (jj < JN) {
+                    double rx = spx[jj] - px, ry = spy[jj] - py;
+                    const double d2u = rx * rx + ry * ry;
+                    if (d2u < P.c_near) nb |= 1ull << jj;
+                    double d2 = d2u;
+                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
+                    if (d2 < P.c_sen) cd |= 1ull << jj;
+                }
+            }
+        }
+        // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
+        pm[(sx * 2 + 0) * AG + at] = NPAD < 64 ? (nb << (el * NPAD)) : nb;
+        pm[(sx * 2 + 1) * AG + at] = cd;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < WPE; ++q) { nearby1 |= pm[(q * 2 + 0) * AG + at]; cand1 |= pm[(q * 2 + 1) * AG + at]; }
+    }
+    if (sx == SB) for (int rep = 0, reps = (NW == 1 ? REPS(10) : REPS(2)); rep < reps; ++rep) {
         FENCE();
         bool collision = false;
         double nd[kTopoMax]; int nj[kTopoMax];
 #pragma unroll
         for (int k = 0; k < kTopoMax; ++k) { nd[k] = INFINITY; nj[k] = -1; }
         u64 nearby[NW], cand[NW];
-        constexpr int JN = NPAD < 64 ? NPAD : 64;               // lanes >= n_a hold NaN positions: never candidates
-        const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
-        // pass A (branch-free, unrolled): candidate mask (norm < d_sen, CPP:658) and "nearby" mask (CPP:161)
+        if constexpr (NW == 1) { nearby[0] = nearby1; cand[0] = cand1; }
+        else {
+            // pass A (branch-free, unrolled): candidate mask (norm < d_sen, CPP:658) and "nearby" mask (CPP:161)
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            u64 nb = 0, cd = 0;
+            for (int w = 0; w < NW; ++w) {
+                u64 nb = 0, cd = 0;
 #pragma unroll 8
-            for (int jj = 0; jj < JN; ++jj) {
-                double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
-                const double d2u = rx * rx + ry * ry;
-                if (d2u < P.c_near) nb |= 1ull << jj;
-                double d2 = d2u;
-                if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                if (d2 < P.c_sen) cd |= 1ull << jj;
+                for (int jj = 0; jj < JN; ++jj) {
+                    double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                    const double d2u = rx * rx + ry * ry;
+                    if (d2u < P.c_near) nb |= 1ull << jj;
+                    double d2 = d2u;
+                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
+                    if (d2 < P.c_sen) cd |= 1ull << jj;
+                }
+                nearby[w] = nb;
+                cand[w] = cd;
             }
-            // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
-            nearby[w] = NPAD < 64 ? (nb << (el * NPAD)) : nb;
-            cand[w] = cd;
         }
         if (i < 64 * NW) cand[NPAD <= 64 ? 0 : (i >> 6)] &= ~(1ull << (i & 63));             // remove self (CPP:672-676)
         // pass B: ordered insertion of the candidates, ascending j => ties keep the lower index first
@@ -467,8 +503,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         }
         STAMP(13);
+        if constexpr (NW > 1) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) snear[w * AG + at] = nearby[w];
+            for (int w = 0; w < NW; ++w) snear[w * AG + at] = nearby[w];
+        }
 #pragma unroll
         for (int k = 0; k < kTopoMax; ++k) {                      // CPP:459-491 collision test on the NEW list
             const bool used = k < P.topo && nj[k] >= 0;
@@ -499,6 +537,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         unsigned word = 0, rword = 0;
         int mlo = 0, mhi = 0;                 // lanes 0..31: ballot (lo, hi halves) of cell b = lane
         int bl = 0; const float best_in = best32;
+        unsigned orw = 0;                     // NW == 1: reversed occupied-bit accumulator
+        const unsigned nlo = (unsigned)nearby1, nhi = (unsigned)(nearby1 >> 32);
         u64 unc = 0;
         const float4 *cq = reinterpret_cast<const float4 *>(cq_e + w * 64);
         static_for<16>([&](auto prc) {
@@ -518,29 +558,37 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 const u64 m_slo = __ballot(d2 < P.csen_lo), m_shi = __ballot(d2 < P.csen_hi);
                 const u64 m_olo = __ballot(d2 < P.cocc_lo), m_ohi = __ballot(d2 < P.cocc_hi);
                 rword = shl1_or_mask(rword, m_slo);
-                mlo = writelane_c<b>((int)(unsigned)m_olo, mlo);
-                mhi = writelane_c<b>((int)(unsigned)(m_olo >> 32), mhi);
+                if constexpr (NW == 1) {
+                    // occupied for lane i  <=>  some NEARBY agent is within r_avoid/2 of this cell (CPP:161,185)
+                    const unsigned t = ((unsigned)m_olo & nlo) | ((unsigned)(m_olo >> 32) & nhi);
+                    orw = shl1_or_mask(orw, __ballot(t != 0));
+                } else {
+                    mlo = writelane_c<b>((int)(unsigned)m_olo, mlo);
+                    mhi = writelane_c<b>((int)(unsigned)(m_olo >> 32), mhi);
+                }
                 unc |= (m_slo ^ m_shi) | (m_olo ^ m_ohi);
             });
         });
         word = __brev(rword);
+        unsigned oword = __brev(orw);
         if (best32 < best_in) bc = w * 32 + bl;
         u64 mym = ((u64)(unsigned)mhi << 32) | (unsigned)mlo;
         if (unc != 0 || wave_exact) {                     // rare: redo this word exactly
-            word = 0;
-            const double2 *cw = cxy_e + w * 32;
+            word = 0; oword = 0;
 #pragma unroll 4
             for (int b = 0; b < 32; ++b) {
-                const double2 g = cw[b];
+                const double2 g = cell64(w * 32 + b);
                 const double rx = g.x - px, ry = g.y - py;
                 const double d2 = rx * rx + ry * ry;
                 if (d2 < P.c_sen) word |= 1u << b;
                 const u64 m = __ballot(d2 < P.c_occ);
                 if (lane == b) mym = m;
+                if (NW == 1 && ((((unsigned)m & nlo) | ((unsigned)(m >> 32) & nhi)) != 0)) oword |= 1u << b;
             }
         }
         sbits[w * AG + at] = word;
-        if (lane < 32) cmask[(size_t)(w * 32 + lane) * NW + aw] = mym;
+        if constexpr (NW == 1) owords[w * AG + at] = oword;
+        else if (lane < 32) cmask[(size_t)(w * 32 + lane) * NW + aw] = mym;
     }
     }
     {   // nearest cell of this split: unambiguous in fp32 unless the runner-up is within tolerance
@@ -555,7 +603,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const int cc = w * 32 + b;
                     const float rx = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf, ry = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf;
                     if (fmaf(rx, rx, ry * ry) <= thr || (wave_exact && unc_min)) {
-                        const double2 g = cxy_e[w * 32 + b];
+                        const double2 g = cell64(w * 32 + b);
                         const double ex = g.x - px, ey = g.y - py;
                         const double d2 = ex * ex + ey * ey;
                         if (d2 < bestd) { bestd = d2; bcd = w * 32 + b; }     // ascending c: first minimum
@@ -569,13 +617,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     __syncthreads();
     // merge the splits' candidates exactly: (d2 in fp64, cell index) lexicographic minimum = first minimum
     double best = INFINITY; bc = 0;
+    for (int rep = 0, reps = REPS(12); rep < reps; ++rep) {
+    FENCE();
+    best = INFINITY; bc = 0;
 #pragma unroll
     for (int s = 0; s < WPE; ++s) {
         const int c = part_c[s * AG + at];
-        const double2 g = cxy_e[c];
+        const double2 g = cell64(c);
         const double ex = g.x - px, ey = g.y - py;
         const double d = ex * ex + ey * ey;
         if (d < best || (d == best && c < bc)) { best = d; bc = c; }
+    }
     }
     const bool in_shape = act && best < P.c_in[es];                    // CPP:889
     if (sx == 0) {
@@ -592,14 +644,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     {
         u64 nearby[NW];
 #pragma unroll
-        for (int q = 0; q < NW; ++q) nearby[q] = in_shape ? snear[q * AG + at] : 0;
+        for (int q = 0; q < NW; ++q) nearby[q] = (NW > 1 && in_shape) ? snear[q * AG + at] : 0;
         for (int rep = 0, reps = REPS(4); rep < reps; ++rep)
         for (int w = 0; w < W; ++w) {
             if (!mine(w)) continue;
             FENCE();
             const unsigned word = sbits[w * AG + at];
             unsigned kw = word;
-            if (in_shape) {
+            if constexpr (NW == 1) {
+                if (in_shape) kw = word & ~owords[w * AG + at];       // occupied bits came out of the scan
+                if (rep == reps - 1) sbits[w * AG + at] = kw;
+            } else if (in_shape) {
                 unsigned it = word;
                 while (it) {
                     int bb[4]; bool occ[4];
@@ -664,6 +719,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // slots of its own words.
     {
         short *row = sidx + (size_t)at * P.g_stride;
+        for (int rep = 0, reps = REPS(11); rep < reps; ++rep) {
+        FENCE();
         int prefix = 0, sbase = 0;
         for (int w = 0; w < W; ++w) {
             const int cnt = pc[w * AG + at];
@@ -676,15 +733,22 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             if (mine(w)) {
                 unsigned it = sbits[w * AG + at], sel = bits;
                 int s = sbase;
-                while (it) {
-                    const int b = __ffs(it) - 1;
-                    it &= it - 1;
-                    if (sel & 1u) { row[s] = (short)(w * 32 + b); ++s; }
-                    sel >>= 1;
+                while (it) {                                   // up to 4 kept bits per trip
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool has = it != 0;
+                        const int b = has ? __ffs(it) - 1 : 0;
+                        it &= it - 1;                          // 0 stays 0
+                        const bool take = has && (sel & 1u);
+                        if (take) row[s] = (short)(w * 32 + b);
+                        s += take ? 1 : 0;
+                        sel >>= 1;
+                    }
                 }
             }
             sbase += __popc(bits);
             prefix += cnt;
+        }
         }
         for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
     }
@@ -733,7 +797,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 const short *row = sidx + (size_t)at * P.g_stride;
                 double num0 = 0.0, num1 = 0.0, den = 0.0;
                 for (int q = 0; q < n_sel; ++q) {
-                    const double2 g = cxy_e[row[q]];
+                    const double2 g = cell64(row[q]);
                     const double x = g.x - px, y = g.y - py;
                     const double z = sqrt(x * x + y * y);
                     // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
@@ -813,7 +877,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const int ncf = sncf[tr];
                     if (half == 0) {                                    // CPP:136
                         if (ncf >> 30) { a = qx - qx; b = qy - qy; }
-                        else { const double2 g = cxy[(size_t)elr * P.cxy_stride + (ncf & 0xFFFF)]; a = g.x - qx; b = g.y - qy; }
+                        else { const double *gr = P.cells + (size_t)(blockIdx.x * EPB + elr) * 2 * P.ng_max; const int cc = ncf & 0xFFFF; a = gr[cc] - qx; b = gr[P.ng_max + cc] - qy; }
                     } else {                                            // CPP:137
                         if (ncf >> 30) { a = ux - ux; b = uy - uy; }
                         else { a = 0.0 - ux; b = 0.0 - uy; }
@@ -827,24 +891,45 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         for (int rep = 0, reps = REPS(8); rep < reps; ++rep) {
             FENCE();
+            // wave per row: lane = slot, so the row's agent position, cell base and output base are wave-uniform
+            // and each store instruction covers 64 consecutive pairs (512 B / 1 KiB contiguous).  CPP:274-291
             const int Gp = P.g_max;
-            const int total = rows * Gp;
-            const int dr = T / Gp, dq = T % Gp;
-            int r = tid / Gp, q = tid % Gp;
-#pragma unroll 2
-            for (int L = tid; L < total; L += T) {                      // CPP:274-291
+            const int wv = tid >> 6, nwv = T >> 6;
+            const int nfull = Gp >> 6, tail = Gp & 63;
+            for (int r = wv; r < rows; r += nwv) {
                 const int elr = EPB > 1 ? r / n_a : 0;
                 const int tr = elr * NPAD + (r - elr * n_a);
-                const int c = sidx[(size_t)tr * P.g_stride + q];
-                double a = 0.0, b = 0.0;
-                if (c >= 0) {
-                    const double2 g = cxy[(size_t)elr * P.cxy_stride + c];
-                    a = g.x - sp[tr]; b = g.y - sp[AG + tr];
+                const double *gr = P.cells + (size_t)(blockIdx.x * EPB + elr) * 2 * P.ng_max;
+                const double qx = sp[tr], qy = sp[AG + tr];
+                const short *srow = sidx + (size_t)tr * P.g_stride;
+                OT2 *orow = out + (size_t)r * PPR + HP;
+                for (int ch = 0; ch < nfull; ++ch) {
+                    const int q = ch * 64 + lane;
+                    const int c = srow[q];
+                    double a = 0.0, b = 0.0;
+                    if (c >= 0) { a = gr[c] - qx; b = gr[P.ng_max + c] - qy; }
+                    OT2 o; o.x = (OT)a; o.y = (OT)b;
+                    orow[q] = o;
                 }
-                OT2 o; o.x = (OT)a; o.y = (OT)b;
-                out[(size_t)r * PPR + HP + q] = o;
-                q += dq; r += dr;
-                if (q >= Gp) { q -= Gp; ++r; }
+            }
+            if (tail) {                                   // the last (G mod 64) slots: several rows per wave pass
+                int tp = 1;
+                while (tp < tail) tp <<= 1;
+                const int rpw = 64 / tp;                  // rows per wave pass
+                const int sub = lane / tp, q = nfull * 64 + (lane & (tp - 1));
+                for (int r0 = wv * rpw; r0 < rows; r0 += nwv * rpw) {
+                    const int r = r0 + sub;
+                    if (r < rows && q < Gp) {
+                        const int elr = EPB > 1 ? r / n_a : 0;
+                        const int tr = elr * NPAD + (r - elr * n_a);
+                        const double *gr = P.cells + (size_t)(blockIdx.x * EPB + elr) * 2 * P.ng_max;
+                        const int c = sidx[(size_t)tr * P.g_stride + q];
+                        double a = 0.0, b = 0.0;
+                        if (c >= 0) { a = gr[c] - sp[tr]; b = gr[P.ng_max + c] - sp[AG + tr]; }
+                        OT2 o; o.x = (OT)a; o.y = (OT)b;
+                        out[(size_t)r * PPR + HP + q] = o;
+                    }
+                }
             }
         }
     }
@@ -937,13 +1022,14 @@ void layout_t(KP &k)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~size_t(15); return (int)o; };
     auto max2 = [](size_t a, size_t b) { return a > b ? a : b; };
-    k.off_cxy = take((size_t)EPB * k.cxy_stride * 16);
+    k.off_cxy = 0;                             // fp64 cells are no longer staged in LDS
     k.off_sp = take((size_t)4 * AG * 8);
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
     k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)k.ngw * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * AG * 4));           // sidx | part_c
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * 2 * AG * 8));       // sidx | pm
+    k.off_partc = take((size_t)WPE * AG * 4);
     k.off_snei = take((size_t)AG * kNeiStride * 2);
     k.off_sncf = take((size_t)AG * 4);
     k.off_snear = take((size_t)NW * AG * 8);

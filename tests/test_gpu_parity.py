@@ -332,7 +332,7 @@ def test_diagnostic_repeat_hooks_do_not_change_results(shapes):
     ra = r_avoid_for(n_a, shapes)
     sy = synthetic_batch(n_env, n_a, shapes, seed=5, assembled_fraction=0.6)
     ref = None
-    for flags in [0] + [(k << 8) | (2 << 12) for k in range(1, 9)]:
+    for flags in [0] + [(k << 8) | (2 << 12) for k in range(1, 13)]:
         sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra, debug_flags=flags)
         sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"]); sb.set_state(sy["p"], sy["dp"]); sb.observe()
         act = torch.zeros((n_env, n_a, 2), device=sb.device)

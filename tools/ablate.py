@@ -13,8 +13,8 @@ from marl_llm_amd.batched import SwarmBatch
 from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
 from marl_llm_amd.synth import synthetic_batch
 
-NAMES = ["forces+prior+integrate", "neighbour search", "cell scan", "occupied filter", "list emit", "reward sums",
-         "obs head pairs", "obs sensed pairs"]
+NAMES = ["forces+prior+integrate", "pair masks", "cell scan", "occupied filter", "rank-select bits", "reward sums",
+         "obs head pairs", "obs sensed pairs", "cell staging", "ordered insertion", "emit walk", "nearest merge"]
 
 
 def run(skip, n_a, E, sy, ra, state, steps=int(os.environ.get('ABLATE_STEPS', '60'))):

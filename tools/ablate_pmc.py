@@ -6,8 +6,8 @@ import csv
 import sys
 
 path, k = sys.argv[1], int(sys.argv[2])
-names = ["full", "forces+prior x3", "neighbour search x3", "cell scan x3", "occupied filter x3", "list emit x3",
-         "reward sums x3", "obs head x3", "obs sensed x3"]
+names = ["full", "forces+prior+integrate", "pair masks", "cell scan", "occupied filter", "rank-select bits", "reward sums",
+         "obs head pairs", "obs sensed pairs", "cell staging", "ordered insertion", "emit walk", "nearest merge"]
 rows = collections.defaultdict(list)
 for r in csv.DictReader(open(path)):
     if "k_env<" in r["Kernel_Name"] and "true>" in r["Kernel_Name"]:
@@ -19,6 +19,7 @@ for cname, v in rows.items():
     per = 5 + k
     print(cname)
     base = None
+    tot = 0.0
     for i, nm in enumerate(names):
         chunk = vals[i * per + 5:(i + 1) * per]
         if not chunk:
@@ -26,4 +27,7 @@ for cname, v in rows.items():
         m = sum(chunk) / len(chunk)
         if base is None:
             base = m
-        print(f"  {nm:22s} {m:14.4g}   per env {m / 4096:9.1f}   phase per env {(m - base) / 2 / 4096:9.1f}")
+        ph = (m - base) / 2 / 4096
+        tot = tot + ph if i else 0.0
+        print(f"  {nm:24s} {m:14.4g}   per env {m / 4096:9.1f}   phase per env {ph:9.1f}")
+    print(f"  sum of phases per env {tot:9.1f}   remainder {base / 4096 - tot:9.1f}")
