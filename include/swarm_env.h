@@ -85,7 +85,8 @@ typedef struct swarm_config {
     int32_t with_prior;             /* training_method == 'llm_rl': compute a_prior (assembly.py:605-624) */
     int32_t obs_dtype;              /* SWARM_F32 (product) or SWARM_F64 (bit-exact parity mode) */
     int32_t device;                 /* HIP device ordinal, -1 = current */
-    int32_t debug_flags;            /* bit 0: force every exact (fp64) fallback path of the fp32 pre-filters */
+    int32_t debug_flags;            /* bit 0: force every exact (fp64) fallback path of the fp32 pre-filters; bit 1: disable the lattice path;
+                                     * bits 8..15: diagnostics (tools/ablate.py) */
     double d_sen;                   /* assembly.py:199  = 0.4 */
     double r_avoid;                 /* assembly.py:124 */
     double size_a;                  /* assembly.py:44   = 0.035 */
@@ -129,6 +130,11 @@ int  swarm_step(swarm_env_t *h, const void *action, int action_dtype,
  * pass on the current state to fill them. */
 int  swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flags,
                        int32_t *sensed_index, int32_t *occupied_index);
+
+/* How many environments currently have target cells that are a row-major subset of a square lattice (the reference's
+ * tiled shapes always are).  When ALL do (and n_agents <= 64), the sensed / occupied bit sets are built by a row walk
+ * over the lattice instead of the all-cells scan; results are identical.  debug_flags bit 1 disables that path. */
+int  swarm_lattice_envs(const swarm_env_t *h);
 
 /* Roofline helper: algorithmic bytes one swarm_step moves (SURVEY.md section 8d accounting). */
 double swarm_step_algorithmic_bytes(const swarm_env_t *h);

@@ -161,6 +161,10 @@ class SwarmBatch:
         check(self.lib, self.handle, self.lib.swarm_get_indices(self.handle, _ptr(nei), _ptr(inf), _ptr(sen), _ptr(occ)))
         return dict(neighbor_index=nei, in_flags=inf, sensed_index=sen, occupied_index=occ)
 
+    def lattice_envs(self):
+        """Number of envs whose target cells were recognised as a lattice subset (fast sensed/occupied path)."""
+        return int(self.lib.swarm_lattice_envs(self.handle))
+
     # -- measurement helpers --------------------------------------------------------------------------
     def algorithmic_bytes_per_step(self):
         return float(self.lib.swarm_step_algorithmic_bytes(self.handle))

@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -43,6 +44,18 @@ namespace {
 constexpr int kTopoMax = 6;
 constexpr int kNeiStride = 8;     // shorts per agent in the LDS neighbour list: 6 ids, [6] = collision flag
 typedef unsigned long long u64;
+
+// Per-environment description of the target cells as a subset of a (rotated) square lattice, when they are one
+// (the reference tiles a silhouette image into square cells and rotates / shifts them: assembly_cfg.py:56-99,
+// assembly.py:175-187).  Cell (column a, row b) sits at o + a*u + b*v and the cell index order is row-major.
+struct LatEnv {
+    double ox, oy;
+    double uxi, uyi, vxi, vyi;    // (p - o) . (uxi, uyi) = column coordinate, (p - o) . (vxi, vyi) = row coordinate
+    float R, Rc;                  // d_sen / l and (r_avoid / 2) / l in lattice steps
+    int nrows, ncols;
+    short rowstart[64];           // cell index of the first cell of each row
+    unsigned long long rowmask[64];   // occupied columns of each row
+};
 
 struct KP {
     int n_env, n_a, ng_max, ngw, topo, g_max, occ_max, obs_dim;
@@ -63,7 +76,11 @@ struct KP {
     unsigned cap_magic; int cap_shift;
     int dbg_phase, dbg_extra;  // diagnostics only (tools/ablate.py): run phase dbg_phase dbg_extra EXTRA times; the
                                // phases are idempotent, so results are unchanged and the extra cost is the phase's cost
-    int off_cxyf, off_partc;
+    int off_cxyf, off_partc, off_lat, off_cov, off_flag;
+    int lattice;               // every env's cells are a lattice subset: row-run path for sensed / occupied bits
+    int lat_rw, lat_cw;        // row half-windows (lattice steps) for d_sen and r_avoid/2
+    double c_near_hi;          // c_near * (1 + 1e-9): pairs in [c_near, c_near_hi) flag the exact occupied-cell path
+    const LatEnv *lat;
     double d_sen, r_avoid, size_a, size2, k_ball, k_wall, c_wall, vel_max, dt;
     double bx0, by1, bx2, by3, w_half, h_half;
     double *p, *dp;
@@ -209,6 +226,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     int *sncf = reinterpret_cast<int *>(smem + P.off_sncf);              // [AG]: nearest cell | in_flag<<30
     u64 *snear = reinterpret_cast<u64 *>(smem + P.off_snear);            // [NW][AG] nearby-agent masks
     unsigned char *pc = smem + P.off_pc;                                 // [word][AG] kept-bit counts
+    u64 *lrm = reinterpret_cast<u64 *>(smem + P.off_lat);                // [EPB][64] lattice row masks
+    short *lrs = reinterpret_cast<short *>(smem + P.off_lat + (size_t)EPB * 64 * 8);   // [EPB][64] row starts
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + P.off_cov);      // [EPB][ngw+1] cells within r_avoid/2 of ANY agent
+    int *sflag = reinterpret_cast<int *>(smem + P.off_flag);             // [AG] per-lane exception flags
 
 #ifdef SWARM_STAMPS
     long long stamp_t[16];
@@ -294,6 +315,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
+    const bool use_lat = (NW == 1) && (P.lattice != 0);
+    if (use_lat) {
+        for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
+        for (int q = tid; q < EPB * (P.ngw + 1); q += T) cov[q] = 0;
+        for (int q = tid; q < EPB * 64; q += T) {
+            const int ek0 = blockIdx.x * EPB + (q >> 6);
+            const LatEnv &Lq = P.lat[ek0 < P.n_env ? ek0 : P.n_env - 1];
+            lrm[q] = Lq.rowmask[q & 63]; lrs[q] = Lq.rowstart[q & 63];
+        }
+        if (sx == 0) sflag[at] = 0;
+    }
     __syncthreads();
     STAMP(1);
 
@@ -433,6 +465,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     if constexpr (NW == 1) {
         constexpr int JQ = (JN + WPE - 1) / WPE;
         u64 nb = 0, cd = 0;
+        bool exc = false;
         for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
             FENCE();
             nb = 0; cd = 0;
@@ -443,12 +476,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     double rx = spx[jj] - px, ry = spy[jj] - py;
                     const double d2u = rx * rx + ry * ry;
                     if (d2u < P.c_near) nb |= 1ull << jj;
+                    else if (d2u < P.c_near_hi) exc = true;      // not "nearby" by a hair: see the occupied-cell filter
                     double d2 = d2u;
                     if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
                     if (d2 < P.c_sen) cd |= 1ull << jj;
                 }
             }
         }
+        if (use_lat && exc) atomicOr(&sflag[at], 1);
         // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
         pm[(sx * 2 + 0) * AG + at] = NPAD < 64 ? (nb << (el * NPAD)) : nb;
         pm[(sx * 2 + 1) * AG + at] = cd;
@@ -529,6 +564,103 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const bool wave_exact = (P.force_exact != 0) || (__any(lane_far) != 0);
     float best32 = INFINITY, second32 = INFINITY; int bc = 0;
     const f2v pxx = {pxf, pxf}, pyy = {pyf, pyf};
+    if (use_lat) {
+        // ---- lattice path.  Row b of the lattice holds the cells of columns rowmask[b]; the columns within
+        // lattice distance rho of the agent form an interval.  Columns inside the radius shrunk by 0.01 steps are
+        // in range for certain (model error ~1e-7 steps), columns outside the radius grown by 0.01 are not; the
+        // (at most a few) columns in between are decided by the reference's exact fp64 test on the stored
+        // coordinates.  Selected cells of a row are consecutive cell indices: one run OR-ed into the bit set.
+        const LatEnv &L = P.lat[es];
+        const float apf = (float)((px - L.ox) * L.uxi + (py - L.oy) * L.uyi);
+        const float bpf = (float)((px - L.ox) * L.vxi + (py - L.oy) * L.vyi);
+        const int nrows = L.nrows, ncols = L.ncols;
+        const u64 *rm = lrm + el * 64;
+        const short *rs = lrs + el * 64;
+        auto row_run = [&](int b, float rho, double cut, float cut_lo, float cut_hi, unsigned *dst, bool dst_shared) {
+            // columns of row b within lattice distance rho of (apf, bpf); exact test d2 < cut on the boundary columns
+            const bool rowok = act && b >= 0 && b < nrows;
+            const float dy = (float)b - bpf;
+            const float ro = rho + 0.01f, ri = rho - 0.01f;
+            const float ho2 = ro * ro - dy * dy, hi2 = ri * ri - dy * dy;
+            const bool any_o = rowok && ho2 > 0.0f;
+            const float ho = __builtin_sqrtf(ho2 > 0.0f ? ho2 : 0.0f);
+            int ao0 = (int)ceilf(apf - ho), ao1 = (int)floorf(apf + ho);
+            int ai0, ai1;
+            if (hi2 > 0.0f) { const float hi = __builtin_sqrtf(hi2); ai0 = (int)ceilf(apf - hi); ai1 = (int)floorf(apf + hi); }
+            else { ai0 = ao1 + 1; ai1 = ao1; }                               // no certain column in this row
+            ao0 = ao0 < 0 ? 0 : ao0; ao1 = ao1 > ncols - 1 ? ncols - 1 : ao1;
+            ai0 = ai0 < ao0 ? ao0 : ai0; ai1 = ai1 > ao1 ? ao1 : ai1;
+            const u64 rowm = any_o ? rm[b < 0 ? 0 : (b > 63 ? 63 : b)] : 0;
+            const int rst = rs[b < 0 ? 0 : (b > 63 ? 63 : b)];
+            auto below = [](int a) -> u64 { return a <= 0 ? 0ull : (a >= 64 ? ~0ull : ((1ull << a) - 1ull)); };
+            u64 acc = (ai1 >= ai0) ? (below(ai1 + 1) & ~below(ai0)) : 0ull;   // certain columns
+            // boundary columns: [ao0, ai0) and (ai1, ao1]
+            u64 bnd = (ao1 >= ao0 ? (below(ao1 + 1) & ~below(ao0)) : 0ull) & ~acc & rowm;
+            while (__any(bnd != 0)) {
+                if (bnd != 0) {
+                    const int a = __ffsll((unsigned long long)bnd) - 1;
+                    bnd &= bnd - 1;
+                    const int c = rst + __popcll(rowm & below(a));
+                    // fp32 copy first (LDS); the exact fp64 test (global) only inside the fp32 guard band
+                    const float fx = cq_e[(c >> 1) * 4 + (c & 1)] - pxf, fy = cq_e[(c >> 1) * 4 + 2 + (c & 1)] - pyf;
+                    const float d2f = fmaf(fx, fx, fy * fy);
+                    bool in = d2f < cut_lo;
+                    if (wave_exact || (!in && d2f < cut_hi)) {
+                        const double2 g = cell64(c);
+                        const double ex = g.x - px, ey = g.y - py;
+                        in = ex * ex + ey * ey < cut;
+                    }
+                    if (in) acc |= 1ull << a;
+                }
+            }
+            const u64 sel = rowm & acc;
+            if (sel != 0) {
+                const int a0 = __ffsll((unsigned long long)sel) - 1;
+                const int idx0 = rst + __popcll(rowm & below(a0));
+                const int cnt = __popcll(sel);
+                // bits [idx0, idx0 + cnt): cnt <= 64, may straddle up to three 32-bit words
+                int pos = idx0, left = cnt;
+                while (left > 0) {
+                    const int wq = pos >> 5, off = pos & 31;
+                    const int take = left < 32 - off ? left : 32 - off;
+                    const unsigned m = (take >= 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << off;
+                    atomicOr(dst_shared ? &dst[wq] : &dst[wq * AG + at], m);
+                    pos += take; left -= take;
+                }
+            }
+        };
+        for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
+            FENCE();
+            const int b0s = (int)floorf(bpf) - P.lat_rw;
+            for (int t = sx; t < 2 * P.lat_rw + 2; t += WPE) row_run(b0s + t, L.R, P.c_sen, P.csen_lo, P.csen_hi, sbits, false);
+            const int b0c = (int)floorf(bpf) - P.lat_cw;
+            for (int t = sx; t < 2 * P.lat_cw + 2; t += WPE) row_run(b0c + t, L.Rc, P.c_occ, P.cocc_lo, P.cocc_hi, cov + el * (P.ngw + 1), true);
+            // nearest cell: value / index tracking only (fp32 with ambiguity detection, as in the generic scan)
+            best32 = INFINITY; second32 = INFINITY; bc = 0;
+            for (int w = 0; w < W; ++w) {
+                if (!mine(w)) continue;
+                int bl = 0; const float best_in = best32;
+                const float4 *cq = reinterpret_cast<const float4 *>(cq_e + w * 64);
+                static_for<16>([&](auto prc) {
+                    constexpr int pr = decltype(prc)::value;
+                    const float4 q = cq[pr];
+                    const f2v gx = {q.x, q.y}, gy = {q.z, q.w};
+                    const f2v rx = gx - pxx, ry = gy - pyy;
+                    const f2v d2v = __builtin_elementwise_fma(rx, rx, ry * ry);
+                    static_for<2>([&](auto hc) {
+                        constexpr int hh = decltype(hc)::value;
+                        constexpr int b = 2 * pr + hh;
+                        const float d2 = hh ? d2v.y : d2v.x;
+                        second32 = __builtin_amdgcn_fmed3f(best32, second32, d2);
+                        const bool lt = d2 < best32;
+                        best32 = lt ? d2 : best32;
+                        bl = lt ? b : bl;
+                    });
+                });
+                if (best32 < best_in) bc = w * 32 + bl;
+            }
+        }
+    } else
     for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
     FENCE();
     best32 = INFINITY; second32 = INFINITY; bc = 0;
@@ -652,6 +784,31 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const unsigned word = sbits[w * AG + at];
             unsigned kw = word;
             if constexpr (NW == 1) {
+                if (use_lat) {
+                    // occupied <=> within r_avoid/2 of ANY agent: the covering agent of a SENSED cell is "nearby"
+                    // (CPP:161) by the triangle inequality, except when its distance sits within rounding of the
+                    // nearby threshold -- those lanes were flagged by the pair pass and are resolved exactly.
+                    const unsigned cw_ = cov[el * (P.ngw + 1) + w];
+                    if (in_shape) {
+                        kw = word & ~cw_;
+                        if (sflag[at] != 0) {
+                            unsigned it = word & cw_;
+                            kw = word;
+                            while (it) {
+                                const int b = __ffs(it) - 1; it &= it - 1;
+                                const double2 g = cell64(w * 32 + b);
+                                u64 nbm = nearby1 >> (NPAD < 64 ? el * NPAD : 0);
+                                bool occ = false;
+                                while (nbm && !occ) {
+                                    const int j = __ffsll((unsigned long long)nbm) - 1; nbm &= nbm - 1;
+                                    const double ex = g.x - spx[j], ey = g.y - spy[j];
+                                    occ = ex * ex + ey * ey < P.c_occ;
+                                }
+                                if (occ) kw &= ~(1u << b);
+                            }
+                        }
+                    }
+                } else
                 if (in_shape) kw = word & ~owords[w * AG + at];       // occupied bits came out of the scan
                 if (rep == reps - 1) sbits[w * AG + at] = kw;
             } else if (in_shape) {
@@ -981,6 +1138,10 @@ struct swarm_env {
     std::string err;
     // device buffers
     double *d_p, *d_dp, *d_cells, *d_cin;
+    LatEnv *d_lat;
+    std::vector<char> lat_ok;      // per env: cells are a lattice subset
+    std::vector<float> lat_R, lat_Rc;
+    bool lattice_disabled;
     int *d_nei, *d_near, *d_inflag, *d_ng, *d_exp_sensed, *d_exp_occ;
 };
 
@@ -1010,6 +1171,79 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Is this cell list a row-major subset of a square lattice (<= 64 x 64)?  Fills `L` (geometry only) if so.
+bool detect_lattice(const double *gx, const double *gy, int n, LatEnv &L)
+{
+    if (n < 2) return false;
+    // lattice step: the closest pair among consecutive cells (cells of one row are consecutive and one step apart)
+    double l2 = INFINITY; int k0 = -1;
+    for (int c = 0; c + 1 < n; ++c) {
+        const double dx = gx[c + 1] - gx[c], dy = gy[c + 1] - gy[c], d2 = dx * dx + dy * dy;
+        if (d2 < l2) { l2 = d2; k0 = c; }
+    }
+    if (!(l2 > 0) || k0 < 0) return false;
+    // the row direction u is one of the (at most four) distinct unit-step directions between consecutive cells
+    // (single-cell rows make consecutive cells vertical neighbours): try each until the order is row-major
+    double cand[4][2]; int ncand = 0;
+    for (int c = 0; c + 1 < n && ncand < 4; ++c) {
+        const double dx = gx[c + 1] - gx[c], dy = gy[c + 1] - gy[c], d2 = dx * dx + dy * dy;
+        if (d2 > l2 * (1.0 + 1e-6)) continue;
+        bool seen = false;
+        for (int q = 0; q < ncand; ++q)
+            if (std::fabs(cand[q][0] - dx) + std::fabs(cand[q][1] - dy) < 1e-6 * std::sqrt(l2)) seen = true;
+        if (!seen) { cand[ncand][0] = dx; cand[ncand][1] = dy; ++ncand; }
+    }
+    std::vector<int> ai((size_t)n), bi((size_t)n);
+    double ux = 0, uy = 0, vx = 0, vy = 0;
+    bool found = false;
+    for (int q = 0; q < ncand && !found; ++q) {
+        ux = cand[q][0]; uy = cand[q][1]; vx = -uy; vy = ux;
+        for (int pass = 0; pass < 2 && !found; ++pass) {
+            bool ok = true;
+            for (int c = 0; c < n && ok; ++c) {
+                const double rx = gx[c] - gx[0], ry = gy[c] - gy[0];
+                const double a = (rx * ux + ry * uy) / l2, b = (rx * vx + ry * vy) / l2;
+                const double ar = std::nearbyint(a), br = std::nearbyint(b);
+                if (std::fabs(a - ar) > 1e-6 || std::fabs(b - br) > 1e-6 || std::fabs(ar) > 4096 || std::fabs(br) > 4096) ok = false;
+                ai[(size_t)c] = (int)ar; bi[(size_t)c] = (int)br;
+            }
+            if (!ok) break;
+            // row-major order: within a row the column increases, rows increase
+            bool order = true, flip = false;
+            for (int c = 0; c + 1 < n; ++c) {
+                if (bi[(size_t)c + 1] == bi[(size_t)c]) { if (ai[(size_t)c + 1] <= ai[(size_t)c]) order = false; }
+                else if (bi[(size_t)c + 1] < bi[(size_t)c]) { flip = true; order = false; }
+            }
+            if (order) { found = true; break; }
+            if (pass == 0 && flip) { vx = -vx; vy = -vy; continue; }      // rows run the other way: mirror v
+            break;
+        }
+    }
+    if (!found) return false;
+    int amin = ai[0], amax = ai[0], bmin = bi[0], bmax = bi[0];
+    for (int c = 0; c < n; ++c) {
+        amin = std::min(amin, ai[(size_t)c]); amax = std::max(amax, ai[(size_t)c]);
+        bmin = std::min(bmin, bi[(size_t)c]); bmax = std::max(bmax, bi[(size_t)c]);
+    }
+    if (amax - amin + 1 > 64 || bmax - bmin + 1 > 64) return false;
+    std::memset(&L, 0, sizeof(L));
+    L.ncols = amax - amin + 1; L.nrows = bmax - bmin + 1;
+    for (int b = 0; b < 64; ++b) L.rowstart[b] = 0;
+    int prev_b = -1;
+    for (int c = 0; c < n; ++c) {
+        const int a = ai[(size_t)c] - amin, b = bi[(size_t)c] - bmin;
+        if (b != prev_b) { if (b < prev_b) return false; L.rowstart[b] = (short)c; prev_b = b; }
+        if (L.rowmask[b] & (1ull << a)) return false;
+        L.rowmask[b] |= 1ull << a;
+    }
+    L.ox = gx[0] - (ai[0] - amin) * ux - (bi[0] - bmin) * vx;
+    L.oy = gy[0] - (ai[0] - amin) * uy - (bi[0] - bmin) * vy;
+    L.uxi = ux / l2; L.uyi = uy / l2; L.vxi = vx / l2; L.vyi = vy / l2;
+    const double l = std::sqrt(l2);
+    L.R = (float)l;                 // caller turns the step length into radii
+    return true;
+}
+
 template <int NPAD>
 void layout_t(KP &k)
 {
@@ -1027,9 +1261,12 @@ void layout_t(KP &k)
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
     k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
-    k.off_sbits = take((size_t)k.ngw * AG * 4);
+    k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
     k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * 2 * AG * 8));       // sidx | pm
     k.off_partc = take((size_t)WPE * AG * 4);
+    k.off_lat = take((size_t)EPB * 64 * (8 + 2));
+    k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
+    k.off_flag = take((size_t)AG * 4);
     k.off_snei = take((size_t)AG * kNeiStride * 2);
     k.off_sncf = take((size_t)AG * 4);
     k.off_snear = take((size_t)NW * AG * 8);
@@ -1144,6 +1381,10 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->have_cells = h->have_state = h->observed = false;
     for (int &a : h->attr_smem) a = -1;
     h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr;
+    h->d_lat = nullptr;
+    h->lat_ok.assign((size_t)cfg->n_env, 0);
+    h->lat_R.assign((size_t)cfg->n_env, 0.0f); h->lat_Rc.assign((size_t)cfg->n_env, 0.0f);
+    h->lattice_disabled = (cfg->debug_flags & 2) != 0;
     h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr;
     h->cells_set.assign((size_t)cfg->n_env, 0);
     h->npad = npad_for(cfg->n_agents);
@@ -1211,6 +1452,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     alloc((void **)&h->d_p, E * 2 * N * 8); alloc((void **)&h->d_dp, E * 2 * N * 8);
     alloc((void **)&h->d_cells, E * 2 * (size_t)k.ng_max * 8); alloc((void **)&h->d_cin, E * 8);
     alloc((void **)&h->d_ng, E * 4);
+    alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
     alloc((void **)&h->d_inflag, E * N * 4);
     if (a == hipSuccess) a = hipMemset(h->d_ng, 0, E * 4);
@@ -1227,6 +1469,8 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     }
     k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag;
     k.cells = h->d_cells; k.n_g = h->d_ng; k.c_in = h->d_cin;
+    k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0;
+    k.c_near_hi = k.c_near * (1.0 + 1e-9);
     *out = h;
     return SWARM_OK;
 }
@@ -1239,7 +1483,7 @@ int swarm_destroy(swarm_env_t *h)
         (void)hipStreamSynchronize(h->stream);
         (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin);
         (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag);
-        (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ);
+        (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
     }
@@ -1281,6 +1525,33 @@ int swarm_set_cells(swarm_env_t *h, int env_begin, int count, const double *cell
     HIP_TRY(h, hipMemcpyAsync(h->d_ng + env_begin, n_g, (size_t)count * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_cin + env_begin, cin.data(), (size_t)count * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));           // cin is a host temporary
+    {   // lattice detection on a host copy of what was uploaded (`cells` may be a device pointer)
+        std::vector<double> hc((size_t)count * row);
+        HIP_TRY(h, hipMemcpy(hc.data(), h->d_cells + (size_t)env_begin * row, (size_t)count * row * 8, hipMemcpyDeviceToHost));
+        std::vector<LatEnv> lat((size_t)count);
+        for (int k = 0; k < count; ++k) {
+            const double *gx = hc.data() + (size_t)k * row, *gy = gx + h->kp.ng_max;
+            LatEnv &L = lat[(size_t)k];
+            std::memset(&L, 0, sizeof(L));
+            const bool ok = !h->lattice_disabled && detect_lattice(gx, gy, n_g[k], L);
+            h->lat_ok[(size_t)(env_begin + k)] = ok ? 1 : 0;
+            if (ok) {
+                const double l = L.R;
+                L.R = (float)(h->kp.d_sen / l); L.Rc = (float)((h->kp.r_avoid / 2.0) / l);
+                h->lat_R[(size_t)(env_begin + k)] = L.R; h->lat_Rc[(size_t)(env_begin + k)] = L.Rc;
+            }
+        }
+        HIP_TRY(h, hipMemcpy(h->d_lat + env_begin, lat.data(), (size_t)count * sizeof(LatEnv), hipMemcpyHostToDevice));
+        bool all = true; float rmax = 0.0f, cmax = 0.0f;
+        for (int e2 = 0; e2 < h->cfg.n_env; ++e2) {
+            if (!h->lat_ok[(size_t)e2]) { all = false; break; }
+            rmax = std::max(rmax, h->lat_R[(size_t)e2]); cmax = std::max(cmax, h->lat_Rc[(size_t)e2]);
+        }
+        h->kp.lattice = all ? 1 : 0;
+        h->kp.lat_rw = (int)std::ceil(rmax + 0.02f);
+        h->kp.lat_cw = (int)std::ceil(cmax + 0.02f);
+        if (h->kp.lat_rw > 30) h->kp.lattice = 0;           // sensing radius of > 30 cells: not worth a row walk
+    }
     for (int k = 0; k < count; ++k) h->cells_set[(size_t)(env_begin + k)] = 1;
     h->have_cells = true;
     for (char c : h->cells_set) if (!c) { h->have_cells = false; break; }
@@ -1358,6 +1629,14 @@ int swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flags
     if (in_flags) HIP_TRY(h, hipMemcpyAsync(in_flags, h->d_inflag, EN * 4, hipMemcpyDefault, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWARM_OK;
+}
+
+int swarm_lattice_envs(const swarm_env_t *h)
+{
+    if (!h) return -1;
+    int n = 0;
+    for (char c : h->lat_ok) n += c ? 1 : 0;
+    return n;
 }
 
 double swarm_step_algorithmic_bytes(const swarm_env_t *h)

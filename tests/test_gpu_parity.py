@@ -101,8 +101,9 @@ CONFIGS = [  # (n_a, n_env, cluster, periodic, with_self, steps)
 ]
 
 
+@pytest.mark.parametrize("flags", [0, 2], ids=["lattice", "generic"])
 @pytest.mark.parametrize("n_a,n_env,cluster,periodic,with_self,steps", CONFIGS)
-def test_batched_trajectories_vs_oracle(oracle, shapes, n_a, n_env, cluster, periodic, with_self, steps):
+def test_batched_trajectories_vs_oracle(oracle, shapes, n_a, n_env, cluster, periodic, with_self, steps, flags):
     """E independent envs with different shapes / rotations, free-running for several steps: the state
     trajectory, all masks and fp64 outputs stay bit-identical to E sequential oracle envs."""
     from marl_llm_amd.shapes import r_avoid_for
@@ -112,8 +113,10 @@ def test_batched_trajectories_vs_oracle(oracle, shapes, n_a, n_env, cluster, per
     ng_max = max(c[2].shape[1] for c in cases) + 3
     cells, n_g = _pad_cells([c[2] for c in cases], ng_max)
     sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=ng_max, r_avoid=ra, is_boundary=not periodic,
-                with_self=with_self, obs_dtype=torch.float64)
+                with_self=with_self, obs_dtype=torch.float64, debug_flags=flags)
     sb.set_cells(cells, n_g, [c[3] for c in cases])
+    # the synthetic shapes are tiled lattices like the reference's: recognised unless the path is disabled
+    assert sb.lattice_envs() == (n_env if flags == 0 else 0)
     p = np.stack([c[0] for c in cases]); dp = np.stack([c[1] for c in cases])
     sb.set_state(p, dp)
     obs0 = sb.observe().cpu().numpy()
@@ -260,11 +263,13 @@ def _adversarial_case(rng, shapes, n_a, ra, d_sen=0.4):
     return np.ascontiguousarray(p), dp, g, l_cell
 
 
-@pytest.mark.parametrize("n_a,n_env,force", [(64, 24, 0), (64, 8, 1), (32, 16, 0), (8, 16, 0), (256, 3, 0), (100, 4, 1)])
+@pytest.mark.parametrize("n_a,n_env,force", [(64, 24, 0), (64, 8, 1), (64, 12, 2), (64, 6, 3), (32, 16, 0), (32, 8, 2), (8, 16, 0),
+                                             (256, 3, 0), (100, 4, 1)])
 def test_threshold_adversarial_inputs(oracle, shapes, n_a, n_env, force):
     """The fp32 pre-filter must hand every borderline decision to the exact fp64 path: masks, flags and the
     step stay bit-identical to the oracle on inputs constructed to sit on the thresholds.  force=1 runs the
-    same inputs with every exact fallback forced (debug flag) -- both must agree with the oracle."""
+    same inputs with every exact fallback forced (debug flag bit 0); bit 1 disables the lattice row walk, so both
+    the lattice and the generic all-cells paths are exercised -- all must agree with the oracle."""
     from marl_llm_amd.shapes import r_avoid_for
     rng = np.random.default_rng(4242 + n_a + force)
     ra = r_avoid_for(n_a, shapes)
@@ -347,3 +352,33 @@ def test_diagnostic_repeat_hooks_do_not_change_results(shapes):
         else:
             for a, b in zip(ref, out):
                 assert torch.equal(a, b), flags
+
+
+def test_non_lattice_cells_fall_back_to_generic_path(oracle, shapes):
+    """Arbitrary (jittered, shuffled) cell sets are not a lattice: the generic scan serves them, same results."""
+    from marl_llm_amd.shapes import r_avoid_for
+    rng = np.random.default_rng(77)
+    n_a, n_env = 32, 6
+    ra = r_avoid_for(n_a, shapes)
+    cases = []
+    for k in range(n_env):
+        p, dp, g, l_cell = make_case(rng, shapes, n_a, 1)
+        if k % 2 == 0:
+            g = g + rng.normal(0, 0.004, g.shape)               # jitter: off-lattice
+        else:
+            g = np.ascontiguousarray(g[:, rng.permutation(g.shape[1])])   # on-lattice points, but not row-major order
+        cases.append((p, dp, np.ascontiguousarray(g), l_cell))
+    ng_max = max(c[2].shape[1] for c in cases)
+    cells, n_g = _pad_cells([c[2] for c in cases], ng_max)
+    sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=ng_max, r_avoid=ra, obs_dtype=torch.float64)
+    sb.set_cells(cells, n_g, [c[3] for c in cases])
+    assert sb.lattice_envs() == 0
+    sb.set_state(np.stack([c[0] for c in cases]), np.stack([c[1] for c in cases]))
+    obs0 = sb.observe().cpu().numpy()
+    idx = sb.indices()
+    for e, (pe, dpe, g, l_cell) in enumerate(cases):
+        o = oracle.get_observation(pe, dpe, g, l_cell, ra)
+        assert np.array_equal(obs0[e], _to_rows(o["obs"]))
+        for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+            assert np.array_equal(idx[k][e].cpu().numpy(), o[k]), (e, k)
+    sb.close()
