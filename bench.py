@@ -25,6 +25,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
+    FETCH correction applied) and committed under profiles/: returned only when it was taken on this exact workload,
+    otherwise None (it cannot be measured from inside this process)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "final_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if workload.startswith(d.get("_workload", "\0")):
+            best = float(d["_traffic_bytes_per_launch"])
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,20 +170,21 @@ def main():
         alg_bytes = sb.algorithmic_bytes_per_step()
         launch_s = kernel_ms * 1e-3 / args.steps
         achieved = alg_bytes / launch_s / 1e9
+        workload = (f"assembly env, {n_a} agents x {E} envs per GPU ({n_a} x {E * world} total), assembled state, "
+                    f"prior-policy actions" if args.state == "assembled" else
+                    f"assembly env, {n_a} agents x {E} envs per GPU ({n_a} x {E * world} total), scatter state, "
+                    f"U(-1,1) actions")
         out = {
             "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"assembly env, {n_a} agents x {E} envs per GPU ({n_a} x {E * world} total), "
-                                   f"{args.state} state, prior-policy actions" if args.state == "assembled" else
-                                   f"assembly env, {n_a} agents x {E} envs per GPU ({n_a} x {E * world} total), "
-                                   f"scatter state, U(-1,1) actions",
+            "config": {"workload": workload,
                        "agents": n_a, "envs_per_gpu": E, "envs_total": E * world, "obs_dtype": "f32",
                        "state_dtype": "f64", "in_shape_fraction": round(in_shape, 3), "seed": args.seed,
                        "parallelism": f"env-sharded x{world}, no collective on the step path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload.split(" (")[0] + ", assembled state" if args.state == "assembled" else "-"),
                          "kernel": "k_env<64,float,true>", "kernel_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

@@ -318,6 +318,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const bool use_lat = (NW == 1) && (P.lattice != 0);
     if (use_lat) {
         for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
+        for (int w = sx; w <= W; w += WPE) reinterpret_cast<unsigned *>(smem + P.off_cmask)[w * AG + at] = 0;   // rank-select bits (region unused until then)
         for (int q = tid; q < EPB * (P.ngw + 1); q += T) cov[q] = 0;
         for (int q = tid; q < EPB * 64; q += T) {
             const int ek0 = blockIdx.x * EPB + (q >> 6);
@@ -465,7 +466,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     if constexpr (NW == 1) {
         constexpr int JQ = (JN + WPE - 1) / WPE;
         u64 nb = 0, cd = 0;
-        bool exc = false;
+        double exc_lo = INFINITY;
         for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
             FENCE();
             nb = 0; cd = 0;
@@ -476,14 +477,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     double rx = spx[jj] - px, ry = spy[jj] - py;
                     const double d2u = rx * rx + ry * ry;
                     if (d2u < P.c_near) nb |= 1ull << jj;
-                    else if (d2u < P.c_near_hi) exc = true;      // not "nearby" by a hair: see the occupied-cell filter
+                    exc_lo = fmin(exc_lo, d2u >= P.c_near ? d2u : INFINITY);   // closest NON-nearby agent (see the occupied-cell filter)
                     double d2 = d2u;
                     if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
                     if (d2 < P.c_sen) cd |= 1ull << jj;
                 }
             }
         }
-        if (use_lat && exc) atomicOr(&sflag[at], 1);
+        if (use_lat && exc_lo < P.c_near_hi) atomicOr(&sflag[at], 1);     // not "nearby" by a hair: resolve exactly
         // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
         pm[(sx * 2 + 0) * AG + at] = NPAD < 64 ? (nb << (el * NPAD)) : nb;
         pm[(sx * 2 + 1) * AG + at] = cd;
@@ -850,8 +851,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // round() equals the integer floor((2 s (n-1) + (G-1)) / (2 (G-1))) exactly; for even G-1 (ties possible) the
     // reference's fp64 expression is evaluated as is.
     unsigned *rsel = reinterpret_cast<unsigned *>(smem + P.off_cmask);      // [W+1][AG] (aliases cmask: consumed)
-    for (int w = sx; w <= W; w += WPE) rsel[w * AG + at] = 0;
-    __syncthreads();
+    if (!use_lat) {                       // lattice mode cleared it up front (the region has no earlier user there)
+        for (int w = sx; w <= W; w += WPE) rsel[w * AG + at] = 0;
+        __syncthreads();
+    }
     for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
         FENCE();
         const bool sub = n_kept > G;
