@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=226)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of the N>1 code path on a one-GPU box: every rank uses cuda:0 and the barrier / "
+                         "max-over-ranks run over gloo (numbers from such a run are meaningless)")
     return ap.parse_args()
 
 
@@ -103,11 +106,16 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no HIP device visible; the env step has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from marl_llm_amd.batched import SwarmBatch
     from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
@@ -159,7 +167,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
