@@ -315,7 +315,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
-    const bool use_lat = (NW == 1) && (P.lattice != 0);
+    const bool use_lat = P.lattice != 0;
     if (use_lat) {
         for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
         for (int w = sx; w <= W; w += WPE) reinterpret_cast<unsigned *>(smem + P.off_cmask)[w * AG + at] = 0;   // rank-select bits (region unused until then)
@@ -462,62 +462,59 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // insertion of the (few) candidates runs on split B.
     constexpr int JN = NPAD < 64 ? NPAD : 64;                   // lanes >= n_a hold NaN positions: never candidates
     const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
-    u64 nearby1 = 0, cand1 = 0;                                  // NW == 1: this lane's complete masks
-    if constexpr (NW == 1) {
+    // every split evaluates 1/WPE of the agents j of each 64-agent group (branch-free, unrolled); the partial masks
+    // are OR-combined through LDS so that every lane ends up with its complete "nearby" masks (split B also with the
+    // candidate masks)
+    u64 nearbyN[NW], candN[NW];
+    {
         constexpr int JQ = (JN + WPE - 1) / WPE;
-        u64 nb = 0, cd = 0;
+        u64 nb[NW], cd[NW];
         double exc_lo = INFINITY;
         for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
             FENCE();
-            nb = 0; cd = 0;
 #pragma unroll
-            for (int q = 0; q < JQ; ++q) {
-                const int jj = sx * JQ + q;
-                if (jj < JN) {
-                    double rx = spx[jj] - px, ry = spy[jj] - py;
-                    const double d2u = rx * rx + ry * ry;
-                    if (d2u < P.c_near) nb |= 1ull << jj;
-                    exc_lo = fmin(exc_lo, d2u >= P.c_near ? d2u : INFINITY);   // closest NON-nearby agent (see the occupied-cell filter)
-                    double d2 = d2u;
-                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                    if (d2 < P.c_sen) cd |= 1ull << jj;
+            for (int w = 0; w < NW; ++w) {
+                nb[w] = 0; cd[w] = 0;
+#pragma unroll
+                for (int q = 0; q < JQ; ++q) {
+                    const int jj = sx * JQ + q;
+                    if (jj < JN) {
+                        double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                        const double d2u = rx * rx + ry * ry;
+                        if (d2u < P.c_near) nb[w] |= 1ull << jj;
+                        exc_lo = fmin(exc_lo, d2u >= P.c_near ? d2u : INFINITY);   // closest NON-nearby agent (see the occupied-cell filter)
+                        double d2 = d2u;
+                        if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
+                        if (d2 < P.c_sen) cd[w] |= 1ull << jj;
+                    }
                 }
             }
         }
         if (use_lat && exc_lo < P.c_near_hi) atomicOr(&sflag[at], 1);     // not "nearby" by a hair: resolve exactly
-        // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
-        pm[(sx * 2 + 0) * AG + at] = NPAD < 64 ? (nb << (el * NPAD)) : nb;
-        pm[(sx * 2 + 1) * AG + at] = cd;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
+            pm[((sx * 2 + 0) * NW + w) * AG + at] = NPAD < 64 ? (nb[w] << (el * NPAD)) : nb[w];
+            pm[((sx * 2 + 1) * NW + w) * AG + at] = cd[w];
+        }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < WPE; ++q) { nearby1 |= pm[(q * 2 + 0) * AG + at]; cand1 |= pm[(q * 2 + 1) * AG + at]; }
+        for (int w = 0; w < NW; ++w) {
+            nearbyN[w] = 0; candN[w] = 0;
+#pragma unroll
+            for (int q = 0; q < WPE; ++q) { nearbyN[w] |= pm[((q * 2 + 0) * NW + w) * AG + at]; candN[w] |= pm[((q * 2 + 1) * NW + w) * AG + at]; }
+        }
     }
-    if (sx == SB) for (int rep = 0, reps = (NW == 1 ? REPS(10) : REPS(2)); rep < reps; ++rep) {
+    const u64 nearby1 = nearbyN[0];
+    if (sx == SB) for (int rep = 0, reps = REPS(10); rep < reps; ++rep) {
         FENCE();
         bool collision = false;
         double nd[kTopoMax]; int nj[kTopoMax];
 #pragma unroll
         for (int k = 0; k < kTopoMax; ++k) { nd[k] = INFINITY; nj[k] = -1; }
         u64 nearby[NW], cand[NW];
-        if constexpr (NW == 1) { nearby[0] = nearby1; cand[0] = cand1; }
-        else {
-            // pass A (branch-free, unrolled): candidate mask (norm < d_sen, CPP:658) and "nearby" mask (CPP:161)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                u64 nb = 0, cd = 0;
-#pragma unroll 8
-                for (int jj = 0; jj < JN; ++jj) {
-                    double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
-                    const double d2u = rx * rx + ry * ry;
-                    if (d2u < P.c_near) nb |= 1ull << jj;
-                    double d2 = d2u;
-                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                    if (d2 < P.c_sen) cd |= 1ull << jj;
-                }
-                nearby[w] = nb;
-                cand[w] = cd;
-            }
-        }
+        for (int w = 0; w < NW; ++w) { nearby[w] = nearbyN[w]; cand[w] = candN[w]; }
         if (i < 64 * NW) cand[NPAD <= 64 ? 0 : (i >> 6)] &= ~(1ull << (i & 63));             // remove self (CPP:672-676)
         // pass B: ordered insertion of the candidates, ascending j => ties keep the lower index first
 #pragma unroll
@@ -784,32 +781,34 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             FENCE();
             const unsigned word = sbits[w * AG + at];
             unsigned kw = word;
-            if constexpr (NW == 1) {
-                if (use_lat) {
-                    // occupied <=> within r_avoid/2 of ANY agent: the covering agent of a SENSED cell is "nearby"
-                    // (CPP:161) by the triangle inequality, except when its distance sits within rounding of the
-                    // nearby threshold -- those lanes were flagged by the pair pass and are resolved exactly.
-                    const unsigned cw_ = cov[el * (P.ngw + 1) + w];
-                    if (in_shape) {
-                        kw = word & ~cw_;
-                        if (sflag[at] != 0) {
-                            unsigned it = word & cw_;
-                            kw = word;
-                            while (it) {
-                                const int b = __ffs(it) - 1; it &= it - 1;
-                                const double2 g = cell64(w * 32 + b);
-                                u64 nbm = nearby1 >> (NPAD < 64 ? el * NPAD : 0);
-                                bool occ = false;
+            if (use_lat) {
+                // occupied <=> within r_avoid/2 of ANY agent: the covering agent of a SENSED cell is "nearby"
+                // (CPP:161) by the triangle inequality, except when its distance sits within rounding of the
+                // nearby threshold -- those lanes were flagged by the pair pass and are resolved exactly.
+                const unsigned cw_ = cov[el * (P.ngw + 1) + w];
+                if (in_shape) {
+                    kw = word & ~cw_;
+                    if (sflag[at] != 0) {
+                        unsigned it = word & cw_;
+                        kw = word;
+                        while (it) {
+                            const int b = __ffs(it) - 1; it &= it - 1;
+                            const double2 g = cell64(w * 32 + b);
+                            bool occ = false;
+                            for (int q = 0; q < NW && !occ; ++q) {
+                                u64 nbm = NW == 1 ? (nearby1 >> (NPAD < 64 ? el * NPAD : 0)) : snear[q * AG + at];
                                 while (nbm && !occ) {
-                                    const int j = __ffsll((unsigned long long)nbm) - 1; nbm &= nbm - 1;
+                                    const int j = q * 64 + __ffsll((unsigned long long)nbm) - 1; nbm &= nbm - 1;
                                     const double ex = g.x - spx[j], ey = g.y - spy[j];
                                     occ = ex * ex + ey * ey < P.c_occ;
                                 }
-                                if (occ) kw &= ~(1u << b);
                             }
+                            if (occ) kw &= ~(1u << b);
                         }
                     }
-                } else
+                }
+                if (rep == reps - 1) sbits[w * AG + at] = kw;
+            } else if constexpr (NW == 1) {
                 if (in_shape) kw = word & ~owords[w * AG + at];       // occupied bits came out of the scan
                 if (rep == reps - 1) sbits[w * AG + at] = kw;
             } else if (in_shape) {
@@ -1265,7 +1264,7 @@ void layout_t(KP &k)
     k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * 2 * AG * 8));       // sidx | pm
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * 2 * NW * AG * 8));  // sidx | pm
     k.off_partc = take((size_t)WPE * AG * 4);
     k.off_lat = take((size_t)EPB * 64 * (8 + 2));
     k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
