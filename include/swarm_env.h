@@ -113,7 +113,16 @@ int  swarm_obs_dim(const swarm_env_t *h);
 int  swarm_set_cells(swarm_env_t *h, int env_begin, int count,
                      const double *cells, const int32_t *n_g, const double *l_cell);
 int  swarm_set_state(swarm_env_t *h, const double *p, const double *dp);   /* [E][2][N], host or device */
+
+/* Batched device-side reset (what AssemblySwarmEnv.reset() does per environment, assembly.py:156-219): a shape set
+ * (HOST arrays: shape_cells[S][2][n_cells_max] in the shape frame = grid_center_origins[s].T, n_g[S], l_cell[S]) is
+ * uploaded once; swarm_reset then draws, for every env, shape index, rotation, offset and the agents' positions /
+ * velocities from a counter-based generator keyed by (seed, episode, env_offset + env) -- no host round trip, any
+ * env range reproducible on any rank -- and runs the observation pass (obs may be NULL). */
+int  swarm_set_shapes(swarm_env_t *h, int n_shapes, const double *shape_cells, const int32_t *n_g, const double *l_cell);
+int  swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_offset, void *obs);
 int  swarm_get_state(swarm_env_t *h, double *p, double *dp);
+int  swarm_get_cells(swarm_env_t *h, double *cells, int32_t *n_g);        /* [E][2][n_cells_max], [E]; host or device */
 
 /* Recompute observations and the obs-derived caches (neighbor_index, in_flags, nearest cell) from the
  * current state: what AssemblySwarmEnv.reset() does with its final _get_obs() (assembly.py:221).
@@ -124,6 +133,11 @@ int  swarm_observe(swarm_env_t *h, void *obs);
  * reward / done / a_prior may be NULL (not written). */
 int  swarm_step(swarm_env_t *h, const void *action, int action_dtype,
                 void *obs, float *reward, uint8_t *done, void *a_prior);
+
+/* Evaluation metrics of the current state, per env: out[E][3] (DEVICE pointer, double) =
+ * [coverage_rate, distribution_uniformity, voronoi_based_uniformity] of
+ * /root/reference/cus_gym/gym/wrappers/customized_envs/assembly_wrapper.py:48-128 (numpy semantics incl. np.var). */
+int  swarm_metrics(swarm_env_t *h, double *out);
 
 /* Index scratch of the LAST swarm_observe/swarm_step (device pointers, any may be NULL).  The first
  * call that asks for sensed/occupied indices allocates the export buffers and re-runs the observation

@@ -28,7 +28,7 @@ _LIB = None
 BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", "swarm_destroy", "swarm_last_error",
                    "swarm_set_stream", "swarm_synchronize", "swarm_obs_dim", "swarm_set_cells", "swarm_set_state",
                    "swarm_get_state", "swarm_observe", "swarm_step", "swarm_get_indices",
-                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs")
+                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_metrics")
 LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior")
 
 
@@ -54,11 +54,15 @@ def load():
     lib.swarm_set_cells.argtypes = [vp, i32, i32, vp, vp, vp]; lib.swarm_set_cells.restype = i32
     lib.swarm_set_state.argtypes = [vp, vp, vp]; lib.swarm_set_state.restype = i32
     lib.swarm_get_state.argtypes = [vp, vp, vp]; lib.swarm_get_state.restype = i32
+    lib.swarm_get_cells.argtypes = [vp, vp, vp]; lib.swarm_get_cells.restype = i32
+    lib.swarm_metrics.argtypes = [vp, vp]; lib.swarm_metrics.restype = i32
     lib.swarm_observe.argtypes = [vp, vp]; lib.swarm_observe.restype = i32
     lib.swarm_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]; lib.swarm_step.restype = i32
     lib.swarm_get_indices.argtypes = [vp, vp, vp, vp, vp]; lib.swarm_get_indices.restype = i32
     lib.swarm_step_algorithmic_bytes.argtypes = [vp]; lib.swarm_step_algorithmic_bytes.restype = dbl
     lib.swarm_lattice_envs.argtypes = [vp]; lib.swarm_lattice_envs.restype = i32
+    lib.swarm_set_shapes.argtypes = [vp, i32, vp, vp, vp]; lib.swarm_set_shapes.restype = i32
+    lib.swarm_reset.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp]; lib.swarm_reset.restype = i32
     lib.swarm_timer_start.argtypes = [vp]; lib.swarm_timer_start.restype = i32
     lib.swarm_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]; lib.swarm_timer_stop.restype = i32
     if lib.swarm_abi_version() != 1:

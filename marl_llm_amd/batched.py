@@ -98,6 +98,38 @@ class SwarmBatch:
                                                               n_g.ctypes.data_as(ctypes.c_void_p),
                                                               l_cell.ctypes.data_as(ctypes.c_void_p)))
 
+    def set_shapes(self, results):
+        """Upload a shape set (the reference's results.pkl layout: 'grid_coords' list of (n_g, 2), 'l_cell' list)
+        for the device-side reset."""
+        grids = [np.asarray(g, dtype=np.float64).T for g in results["grid_coords"]]       # (2, n_g), assembly.py:164
+        S = len(grids)
+        cells = np.zeros((S, 2, self.n_cells_max))
+        n_g = np.zeros(S, np.int32)
+        for k, g in enumerate(grids):
+            if g.shape[1] > self.n_cells_max:
+                raise SwarmError("shape %d has %d cells > n_cells_max=%d" % (k, g.shape[1], self.n_cells_max))
+            n_g[k] = g.shape[1]; cells[k, :, : g.shape[1]] = g
+        l_cell = np.ascontiguousarray(results["l_cell"], dtype=np.float64)
+        check(self.lib, self.handle, self.lib.swarm_set_shapes(self.handle, S, cells.ctypes.data_as(ctypes.c_void_p),
+                                                               n_g.ctypes.data_as(ctypes.c_void_p),
+                                                               l_cell.ctypes.data_as(ctypes.c_void_p)))
+
+    def reset(self, seed, episode=0, env_offset=0):
+        """Batched device-side reset (swarm_reset): returns the first observation tensor."""
+        self._flip ^= 1
+        obs = self._obs[self._flip]
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_reset(self.handle, int(seed), int(episode), int(env_offset), _ptr(obs)))
+        return obs
+
+    def get_cells(self):
+        """(cells [E,2,n_cells_max] float64, n_g [E] int32) currently on the device (numpy copies)."""
+        cells = np.empty((self.n_env, 2, self.n_cells_max)); n_g = np.empty(self.n_env, np.int32)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_get_cells(self.handle, cells.ctypes.data_as(ctypes.c_void_p),
+                                                              n_g.ctypes.data_as(ctypes.c_void_p)))
+        return cells, n_g
+
     def set_state(self, p, dp):
         """p, dp [E, 2, N] float64 (numpy or torch)."""
         keep = []
@@ -160,6 +192,14 @@ class SwarmBatch:
         self._sync_stream()
         check(self.lib, self.handle, self.lib.swarm_get_indices(self.handle, _ptr(nei), _ptr(inf), _ptr(sen), _ptr(occ)))
         return dict(neighbor_index=nei, in_flags=inf, sensed_index=sen, occupied_index=occ)
+
+    def metrics(self):
+        """[E, 3] float64 tensor: coverage_rate, distribution_uniformity, voronoi_based_uniformity per env
+        (assembly_wrapper.py:48-128) of the current state."""
+        out = torch.empty((self.n_env, 3), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_metrics(self.handle, _ptr(out)))
+        return out
 
     def lattice_envs(self):
         """Number of envs whose target cells were recognised as a lattice subset (fast sensed/occupied path)."""

@@ -1100,6 +1100,179 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 }
 
 // -------------------------------------------------------------------------------------------------
+// batched reset: AssemblySwarmEnv.reset(), ENV:156-219, for every environment at once.
+// Counter-based generator: draw k of environment g in episode ep under `seed` is
+//     u = (mix64(mix64(mix64(seed + GOLD*(ep+1)) ^ g) + GOLD*(k+1)) >> 11) * 2^-53   in [0, 1)
+// (splitmix64 finaliser), so any env range can be generated on any rank without communication.  Draw slots mirror
+// the reference's order: 0 shape index (:160), 1 angle (:175), 2-3 the discarded offset (:182), 4-5 offset (:184-185),
+// 6 branch coin (:202), 7-8 cluster centre (:207-208), then per agent x, y (:203-208) and vx, vy (:215).
+// -------------------------------------------------------------------------------------------------
+struct ShapeSet {
+    int n_shapes;
+    const double *cells;      // [S][2][ng_max], shape frame (ENV: grid_center_origins[s].T)
+    const int *n_g;           // [S]
+    const double *l_cell;     // [S]
+    const double *c_in;       // [S] in-shape cut-off
+    const LatEnv *lat;        // [S] lattice of the un-rotated shape (nrows == 0: not a lattice)
+};
+
+__host__ __device__ inline unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__host__ __device__ inline double reset_u01(unsigned long long key, unsigned k)
+{
+    return (double)(mix64(key + 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1)) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void __launch_bounds__(256)
+k_reset(const KP P, const ShapeSet S, const unsigned long long seed, const unsigned long long episode,
+        const long long env_offset, double *cells_out, int *ng_out, double *cin_out, LatEnv *lat_out)
+{
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long key = mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (episode + 1)) ^ (unsigned long long)(env_offset + e));
+    const double W = P.w_half, H = P.h_half;
+    int s = (int)(reset_u01(key, 0) * S.n_shapes);
+    s = s >= S.n_shapes ? S.n_shapes - 1 : s;
+    const double ang = M_PI * (2.0 * reset_u01(key, 1) - 1.0);
+    const double cs = cos(ang), sn = sin(ang);                       // rotate_matrix = [[c, s], [-s, c]], ENV:177
+    const double offx = (-W + 1) + reset_u01(key, 4) * (2 * W - 2);
+    const double offy = (-H + 1) + reset_u01(key, 5) * (2 * H - 2);
+    const int ng = S.n_g[s];
+    const double *sx_ = S.cells + (size_t)s * 2 * P.ng_max, *sy_ = sx_ + P.ng_max;
+    double *gx = cells_out + (size_t)e * 2 * P.ng_max, *gy = gx + P.ng_max;
+    for (int c = tid; c < P.ng_max; c += blockDim.x) {
+        double x = 0.0, y = 0.0;
+        if (c < ng) { x = cs * sx_[c] + sn * sy_[c] + offx; y = -sn * sx_[c] + cs * sy_[c] + offy; }   // ENV:178,187
+        gx[c] = x; gy[c] = y;
+    }
+    if (tid == 0) {
+        ng_out[e] = ng; cin_out[e] = S.c_in[s];
+        LatEnv L = S.lat[s];
+        if (L.nrows > 0) {          // rotate / shift the shape's lattice: u' = R u, v' = R v, o' = R o + offset
+            // shape-frame basis from the stored inverse basis: u = uxi / |uxi|^2
+            const double iu = 1.0 / (L.uxi * L.uxi + L.uyi * L.uyi), iv = 1.0 / (L.vxi * L.vxi + L.vyi * L.vyi);
+            const double ux = L.uxi * iu, uy = L.uyi * iu, vx = L.vxi * iv, vy = L.vyi * iv;
+            const double rux = cs * ux + sn * uy, ruy = -sn * ux + cs * uy;
+            const double rvx = cs * vx + sn * vy, rvy = -sn * vx + cs * vy;
+            const double rox = cs * L.ox + sn * L.oy + offx, roy = -sn * L.ox + cs * L.oy + offy;
+            L.ox = rox; L.oy = roy;
+            L.uxi = rux / iu; L.uyi = ruy / iu; L.vxi = rvx / iv; L.vyi = rvy / iv;
+        }
+        lat_out[e] = L;
+    }
+    // agents (ENV:202-215)
+    const int N = P.n_a;
+    const bool spread = (2.0 * reset_u01(key, 6) - 1.0) > 0;
+    const double cx = (-W + 1) + reset_u01(key, 7) * (2 * W - 2), cy = (-H + 1) + reset_u01(key, 8) * (2 * H - 2);
+    for (int i = tid; i < N; i += blockDim.x) {
+        const double ux_ = reset_u01(key, 16 + i), uy_ = reset_u01(key, 16 + N + i);
+        double x, y;
+        if (spread) { x = -W + ux_ * (2 * W); y = -H + uy_ * (2 * H); }
+        else { x = (2.0 * ux_ - 1.0) + cx; y = (2.0 * uy_ - 1.0) + cy; }
+        P.p[(size_t)e * 2 * N + i] = x; P.p[(size_t)e * 2 * N + N + i] = y;
+        P.dp[(size_t)e * 2 * N + i] = -0.5 + reset_u01(key, 16 + 2 * N + i);
+        P.dp[(size_t)e * 2 * N + N + i] = -0.5 + reset_u01(key, 16 + 3 * N + i);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// evaluation metrics: AssemblySwarmWrapper.coverage_rate / distribution_uniformity /
+// voronoi_based_uniformity, /root/reference/cus_gym/gym/wrappers/customized_envs/assembly_wrapper.py:48-128, per env.
+// fp64 in numpy's operation order, including np.var's two-pass form and numpy's pairwise summation (blocks of 8
+// accumulators up to 128 elements, recursive halves above), so the values are bit-identical to the Python loops.
+// -------------------------------------------------------------------------------------------------
+__device__ double np_pairwise_sum(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+// (np.var(v) - min(v)) / (max(v) - min(v)), assembly_wrapper.py:96-99,125-126; `tmp` holds n doubles of scratch
+__device__ double np_var_metric(const double *v, double *tmp, int n)
+{
+    const double mean = np_pairwise_sum(v, n) / n;
+    double mn = v[0], mx = v[0];
+    for (int i = 0; i < n; ++i) {
+        const double d = v[i] - mean;
+        tmp[i] = d * d;
+        mn = v[i] < mn ? v[i] : mn; mx = v[i] > mx ? v[i] : mx;
+    }
+    const double var = np_pairwise_sum(tmp, n) / n;
+    return (var - mn) / (mx - mn);
+}
+
+__global__ void __launch_bounds__(256)
+k_metrics(const KP P, double *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = P.n_a, e = blockIdx.x, tid = threadIdx.x;
+    double *px = reinterpret_cast<double *>(smem), *py = px + N;       // [N], [N]
+    double *val = py + N, *tmp = val + N;                              // [N] per-agent values, [N] scratch
+    int *cnt = reinterpret_cast<int *>(tmp + N);                       // [N] Voronoi counts, then [1] coverage count
+    const int ng = P.n_g[e];
+    const double *gx = P.cells + (size_t)e * 2 * P.ng_max, *gy = gx + P.ng_max;
+    for (int i = tid; i < N; i += blockDim.x) {
+        px[i] = P.p[(size_t)e * 2 * N + i]; py[i] = P.p[(size_t)e * 2 * N + N + i];
+        cnt[i] = 0;
+    }
+    if (tid == 0) cnt[N] = 0;
+    __syncthreads();
+    // coverage (assembly_wrapper.py:58-73) and Voronoi owner (:110-121) of every cell
+    const double half = P.r_avoid / 2;
+    for (int c = tid; c < ng; c += blockDim.x) {
+        bool covered = false;
+        double best = 0.0; int owner = 0;
+        for (int j = 0; j < N; ++j) {
+            const double dx = px[j] - gx[c], dy = py[j] - gy[c];
+            const double d = sqrt(dx * dx + dy * dy);                 // np.linalg.norm(axis=0)
+            covered = covered || (d < half);
+            if (j == 0 || d < best) { best = d; owner = j; }          // np.argmin: first minimum
+        }
+        if (covered) atomicAdd(&cnt[N], 1);
+        atomicAdd(&cnt[owner], 1);
+    }
+    // minimum non-zero distance of every agent (:85-93)
+    for (int i = tid; i < N; i += blockDim.x) {
+        double m = INFINITY;
+        for (int j = 0; j < N; ++j) {
+            const double dx = px[j] - px[i], dy = py[j] - py[i];
+            const double d = sqrt(dx * dx + dy * dy);
+            if (d != 0 && d < m) m = d;
+        }
+        val[i] = m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        out[(size_t)e * 3 + 0] = (double)cnt[N] / ng;
+        out[(size_t)e * 3 + 1] = np_var_metric(val, tmp, N);
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += blockDim.x) val[i] = (double)cnt[i];
+    __syncthreads();
+    if (tid == 0) out[(size_t)e * 3 + 2] = np_var_metric(val, tmp, N);
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 
@@ -1141,6 +1314,12 @@ struct swarm_env {
     // device buffers
     double *d_p, *d_dp, *d_cells, *d_cin;
     LatEnv *d_lat;
+    // shape set for the device-side reset
+    int n_shapes;
+    double *d_shape_cells, *d_shape_l, *d_shape_cin;
+    int *d_shape_ng;
+    LatEnv *d_shape_lat;
+    bool shapes_lattice; float shapes_rmax, shapes_cmax;
     std::vector<char> lat_ok;      // per env: cells are a lattice subset
     std::vector<float> lat_R, lat_Rc;
     bool lattice_disabled;
@@ -1384,6 +1563,8 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     for (int &a : h->attr_smem) a = -1;
     h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr;
     h->d_lat = nullptr;
+    h->n_shapes = 0; h->d_shape_cells = h->d_shape_l = h->d_shape_cin = nullptr; h->d_shape_ng = nullptr; h->d_shape_lat = nullptr;
+    h->shapes_lattice = false; h->shapes_rmax = h->shapes_cmax = 0.0f;
     h->lat_ok.assign((size_t)cfg->n_env, 0);
     h->lat_R.assign((size_t)cfg->n_env, 0.0f); h->lat_Rc.assign((size_t)cfg->n_env, 0.0f);
     h->lattice_disabled = (cfg->debug_flags & 2) != 0;
@@ -1486,6 +1667,7 @@ int swarm_destroy(swarm_env_t *h)
         (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin);
         (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag);
         (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat);
+        (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
     }
@@ -1561,6 +1743,66 @@ int swarm_set_cells(swarm_env_t *h, int env_begin, int count, const double *cell
     return SWARM_OK;
 }
 
+int swarm_set_shapes(swarm_env_t *h, int n_shapes, const double *shape_cells, const int32_t *n_g, const double *l_cell)
+{
+    if (!h) return SWARM_ERR_INVALID;
+    if (n_shapes < 1 || !shape_cells || !n_g || !l_cell) return fail(h, SWARM_ERR_INVALID, "swarm_set_shapes: bad argument");
+    const size_t row = (size_t)2 * h->kp.ng_max;
+    std::vector<double> cin((size_t)n_shapes);
+    std::vector<LatEnv> lat((size_t)n_shapes);
+    bool all = true; float rmax = 0.0f, cmax = 0.0f;
+    for (int k = 0; k < n_shapes; ++k) {
+        if (n_g[k] < 1 || n_g[k] > h->cfg.n_cells_max) return fail(h, SWARM_ERR_INVALID, "swarm_set_shapes: n_g must be in [1, n_cells_max]");
+        if (!(l_cell[k] > 0)) return fail(h, SWARM_ERR_INVALID, "swarm_set_shapes: l_cell must be positive");
+        cin[(size_t)k] = cut_lt(std::sqrt(2) * l_cell[k] / 2);
+        LatEnv &L = lat[(size_t)k];
+        std::memset(&L, 0, sizeof(L));
+        const double *gx = shape_cells + (size_t)k * row, *gy = gx + h->kp.ng_max;
+        if (!h->lattice_disabled && detect_lattice(gx, gy, n_g[k], L)) {
+            const double l = L.R;
+            L.R = (float)(h->kp.d_sen / l); L.Rc = (float)((h->kp.r_avoid / 2.0) / l);
+            rmax = std::max(rmax, L.R); cmax = std::max(cmax, L.Rc);
+        } else { std::memset(&L, 0, sizeof(L)); all = false; }
+    }
+    DeviceGuard g(h->device);
+    (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
+    h->d_shape_cells = h->d_shape_l = h->d_shape_cin = nullptr; h->d_shape_ng = nullptr; h->d_shape_lat = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&h->d_shape_cells, (size_t)n_shapes * row * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_shape_l, (size_t)n_shapes * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_shape_cin, (size_t)n_shapes * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_shape_ng, (size_t)n_shapes * 4));
+    HIP_TRY(h, hipMalloc((void **)&h->d_shape_lat, (size_t)n_shapes * sizeof(LatEnv)));
+    HIP_TRY(h, hipMemcpy(h->d_shape_cells, shape_cells, (size_t)n_shapes * row * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_shape_l, l_cell, (size_t)n_shapes * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_shape_cin, cin.data(), (size_t)n_shapes * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_shape_ng, n_g, (size_t)n_shapes * 4, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_shape_lat, lat.data(), (size_t)n_shapes * sizeof(LatEnv), hipMemcpyHostToDevice));
+    h->n_shapes = n_shapes; h->shapes_lattice = all; h->shapes_rmax = rmax; h->shapes_cmax = cmax;
+    return SWARM_OK;
+}
+
+int swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_offset, void *obs)
+{
+    if (!h) return SWARM_ERR_INVALID;
+    if (h->n_shapes < 1) return fail(h, SWARM_ERR_STATE, "swarm_reset: no shape set (swarm_set_shapes)");
+    DeviceGuard g(h->device);
+    ShapeSet S;
+    S.n_shapes = h->n_shapes; S.cells = h->d_shape_cells; S.n_g = h->d_shape_ng; S.l_cell = h->d_shape_l;
+    S.c_in = h->d_shape_cin; S.lat = h->d_shape_lat;
+    hipLaunchKernelGGL(k_reset, dim3(h->cfg.n_env), dim3(256), 0, h->stream, h->kp, S, (unsigned long long)seed,
+                       (unsigned long long)episode, (long long)env_offset, h->d_cells, h->d_ng, h->d_cin, h->d_lat);
+    HIP_TRY(h, hipGetLastError());
+    std::fill(h->cells_set.begin(), h->cells_set.end(), 1);
+    std::fill(h->lat_ok.begin(), h->lat_ok.end(), h->shapes_lattice ? 1 : 0);
+    h->have_cells = h->have_state = true;
+    h->kp.lattice = h->shapes_lattice ? 1 : 0;
+    h->kp.lat_rw = (int)std::ceil(h->shapes_rmax + 0.02f);
+    h->kp.lat_cw = (int)std::ceil(h->shapes_cmax + 0.02f);
+    if (h->kp.lat_rw > 30) h->kp.lattice = 0;
+    h->observed = false;
+    return swarm_observe(h, obs);
+}
+
 int swarm_set_state(swarm_env_t *h, const double *p, const double *dp)
 {
     if (!h) return SWARM_ERR_INVALID;
@@ -1572,6 +1814,27 @@ int swarm_set_state(swarm_env_t *h, const double *p, const double *dp)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_state = true;
     h->observed = false;
+    return SWARM_OK;
+}
+
+int swarm_metrics(swarm_env_t *h, double *out)
+{
+    if (!h || !out) return SWARM_ERR_INVALID;
+    if (!h->have_cells || !h->have_state) return fail(h, SWARM_ERR_STATE, "swarm_metrics: cells / state not set");
+    DeviceGuard g(h->device);
+    const size_t smem = (size_t)h->cfg.n_agents * (4 * 8 + 4) + 16;
+    hipLaunchKernelGGL(k_metrics, dim3(h->cfg.n_env), dim3(256), smem, h->stream, h->kp, out);
+    HIP_TRY(h, hipGetLastError());
+    return SWARM_OK;
+}
+
+int swarm_get_cells(swarm_env_t *h, double *cells, int32_t *n_g)
+{
+    if (!h) return SWARM_ERR_INVALID;
+    DeviceGuard g(h->device);
+    if (cells) HIP_TRY(h, hipMemcpyAsync(cells, h->d_cells, (size_t)h->cfg.n_env * 2 * h->kp.ng_max * 8, hipMemcpyDefault, h->stream));
+    if (n_g) HIP_TRY(h, hipMemcpyAsync(n_g, h->d_ng, (size_t)h->cfg.n_env * 4, hipMemcpyDefault, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWARM_OK;
 }
 

@@ -123,6 +123,7 @@ class AssemblySwarmEnv(_EnvBase):
         self.shape_frequency = np.zeros(len(self.l_cells))
         self.n_cells_max = int(max(self.n_gs))
         self._batch = None
+        self._shapes_uploaded = False
 
     # ------------------------------------------------------------------ backend
     def _backend(self):
@@ -172,9 +173,26 @@ class AssemblySwarmEnv(_EnvBase):
         return dict(cells=cells, n_g=n_g, l_cell=l_cell, p=p, dp=dp, shape_index=shape_idx)
 
     def reset_tensor(self):
-        """reset() returning the device observation tensor [E, N, D]."""
+        """reset() returning the device observation tensor [E, N, D].
+
+        rng="global" (default): the reference's draw order from numpy's global RNG on the host (seed-for-seed parity,
+        assembly.py:156-219).  rng="counter": the same draws from a per-(seed, episode, env) numpy stream on the host.
+        rng="device": the batched device-side reset (swarm_reset: counter-based generator on the GPU, no host work)."""
         self.simulation_time = 0
         self._episode = getattr(self, "_episode", -1) + 1
+        self.d_sen = 0.4                                                              # :199
+        self.boundary_pos = np.array([-self.boundary_width_half, self.boundary_height_half,
+                                      self.boundary_width_half, -self.boundary_height_half], dtype=np.float64)
+        if self._rng_mode == "device":
+            b = self._backend()
+            if not getattr(self, "_shapes_uploaded", False):
+                b.set_shapes(dict(grid_coords=self.grid_center_origins, l_cell=self.l_cells))
+                self._shapes_uploaded = True
+            obs = b.reset(self._seed, self._episode, getattr(self, "env_offset", 0))
+            self._cells, self._n_g = b.get_cells()
+            self._l_cell = np.zeros(self.n_envs)         # per-env l_cell stays on the device in this mode
+            self._cells_dirty = False
+            return obs
         s = self._sample_reset()
         self._cells, self._n_g, self._l_cell = s["cells"], s["n_g"], s["l_cell"]
         self.shape_index = s["shape_index"]
@@ -313,6 +331,16 @@ class AssemblySwarmWrapper(_WrapperBase):
         if name.startswith("_"):
             raise AttributeError(name)
         return getattr(self.env, name)
+
+    # evaluation metrics (assembly_wrapper.py:48-128), computed on the device; env 0 when several envs are batched
+    def coverage_rate(self):
+        return float(self.env._backend().metrics()[0, 0].item())
+
+    def distribution_uniformity(self):
+        return float(self.env._backend().metrics()[0, 1].item())
+
+    def voronoi_based_uniformity(self):
+        return float(self.env._backend().metrics()[0, 2].item())
 
     def reset(self, **kw):
         return self.env.reset(**kw)

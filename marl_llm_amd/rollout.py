@@ -1,0 +1,100 @@
+"""Device-resident rollout loop.
+
+The reference rolls out on the host: `torch.Tensor(obs)` -> policy MLP on the CPU -> numpy actions -> `env.step` -> numpy
+ring buffer (train_assembly.py:91-111, maddpg.py:72-87, agents.py:69-96, buffer_agent.py:67-128).  Once the env emits
+`[E, N, D]` device tensors that round trip is the bottleneck, so this module keeps the whole transition on the GPU:
+
+* `PolicyMLP`     -- the reference's actor shape (networks.py:6-44: 4 x Linear, leaky-ReLU, tanh out) as a plain torch
+                     module (hipBLASLt GEMMs; nothing to hand-write: agents are batch rows).
+* `DeviceReplay`  -- the ring buffer of buffer_agent.py:13-128 with one row per (env, agent) transition, as device tensors.
+* `rollout`       -- obs -> policy -> exploration noise (agents.py:82-96 continuous branch) -> env.step_tensor -> push.
+
+PyTorch is plumbing here (device memory, GEMMs); the environment step is the HIP library.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class PolicyMLP(nn.Module):
+    def __init__(self, obs_dim=192, act_dim=2, hidden_dim=180):          # assembly_cfg.py:185 hidden_dim = 180
+        super().__init__()
+        self.fc1 = nn.Linear(obs_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc3 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc4 = nn.Linear(hidden_dim, act_dim)
+
+    def forward(self, x):
+        h = F.leaky_relu(self.fc1(x))
+        h = F.leaky_relu(self.fc2(h))
+        h = F.leaky_relu(self.fc3(h))
+        return torch.tanh(self.fc4(h))
+
+
+class DeviceReplay:
+    """Ring buffer of per-agent transitions on the device (buffer_agent.py:40-128 semantics: rows are appended in
+    blocks of one env step = E*N rows; a block that would overflow the end is written flush with the end)."""
+
+    def __init__(self, capacity_rows, obs_dim, act_dim, device, obs_dtype=torch.float32):
+        self.capacity = int(capacity_rows)
+        z = lambda d, dt=torch.float32: torch.zeros((self.capacity, d), dtype=dt, device=device)
+        self.obs, self.next_obs = z(obs_dim, obs_dtype), z(obs_dim, obs_dtype)
+        self.act, self.act_prior = z(act_dim), z(act_dim)
+        self.rew, self.done = z(1), z(1)
+        self.filled_i = 0
+        self.curr_i = 0
+
+    def __len__(self):
+        return self.filled_i
+
+    def push(self, obs, act, rew, next_obs, done, act_prior=None):
+        """obs/next_obs [E,N,D], act/act_prior [E,N,2], rew/done [E,N]."""
+        n = obs.shape[0] * obs.shape[1]
+        if n > self.capacity:
+            raise ValueError("one env step (%d rows) does not fit in the replay buffer (%d rows)" % (n, self.capacity))
+        if self.curr_i + n > self.capacity:                       # buffer_agent.py:97-100
+            self.curr_i = self.capacity - n
+        s = slice(self.curr_i, self.curr_i + n)
+        self.obs[s] = obs.reshape(n, -1); self.next_obs[s] = next_obs.reshape(n, -1)
+        self.act[s] = act.reshape(n, -1)
+        self.rew[s] = rew.reshape(n, 1); self.done[s] = done.reshape(n, 1).to(self.done.dtype)
+        if act_prior is not None:
+            self.act_prior[s] = act_prior.reshape(n, -1)
+        self.curr_i += n
+        if self.filled_i < self.capacity:
+            self.filled_i = min(self.capacity, self.filled_i + n)
+        if self.curr_i == self.capacity:
+            self.curr_i = 0
+
+    def sample(self, batch, generator=None):
+        idx = torch.randint(0, self.filled_i, (batch,), device=self.obs.device, generator=generator)
+        return self.obs[idx], self.act[idx], self.rew[idx], self.next_obs[idx], self.done[idx], self.act_prior[idx]
+
+
+@torch.no_grad()
+def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, generator=None):
+    """Run `steps` env steps entirely on the device.
+
+    env   : object with step_tensor(action[E,N,2]) -> (obs[E,N,D], rew[E,N], done[E,N], a_prior[E,N,2]|None)
+            (marl_llm_amd.env.AssemblySwarmEnv, or a SwarmBatch through `step`)
+    obs   : current observation tensor [E,N,D] (from reset_tensor / the previous rollout)
+    Returns (last obs, mean reward per step tensor [steps])."""
+    step = env.step_tensor if hasattr(env, "step_tensor") else env.step
+    E, N, D = obs.shape
+    rews = torch.zeros(steps, device=obs.device)
+    for t in range(steps):
+        x = obs.reshape(E * N, D)
+        if x.dtype != torch.float32:
+            x = x.float()
+        act = policy(x)
+        if epsilon > 0 and float(torch.rand((), device=obs.device, generator=generator)) < epsilon:   # agents.py:89-91
+            act = torch.rand(act.shape, device=obs.device, generator=generator) * 2 - 1
+        elif noise_scale > 0:                                                                          # agents.py:93-96
+            act = (act + noise_scale * torch.randn(act.shape, device=obs.device, generator=generator)).clamp_(-1, 1)
+        act = act.reshape(E, N, 2)
+        next_obs, rew, done, pri = step(act)
+        if replay is not None:
+            replay.push(obs, act, rew, next_obs, done, pri)
+        rews[t] = rew.mean()
+        obs = next_obs
+    return obs, rews

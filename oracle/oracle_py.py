@@ -329,3 +329,26 @@ def ref_step(ref, p, dp, a, grid, neighbor_index, l_cell, r_avoid, d_sen=D_SEN, 
                          boundary, is_periodic, o["occupied_index"])
     o.update(p=p, dp=dp, reward=rew, a_prior=a_prior, done=np.zeros((1, p.shape[1]), bool))
     return o
+
+
+def wrapper_metrics(p, grid, r_avoid):
+    """AssemblySwarmWrapper.coverage_rate / distribution_uniformity / voronoi_based_uniformity restated
+    (/root/reference/cus_gym/gym/wrappers/customized_envs/assembly_wrapper.py:48-128): Python loops over cells and
+    agents with numpy norms, np.var, np.argmin -- the same calls in the same order."""
+    n_a, n_g = p.shape[1], grid.shape[1]
+    occupied = 0
+    for gi in range(n_g):                                              # :58-69
+        if (np.linalg.norm(p - grid[:, [gi]], axis=0) < r_avoid / 2).any():
+            occupied += 1
+    m1 = occupied / n_g
+    min_dist = []
+    for i in range(n_a):                                               # :85-93
+        d = np.linalg.norm(p - p[:, [i]], axis=0)
+        min_dist.append(np.min(d[d != 0]))
+    with np.errstate(all="ignore"):
+        m2 = (np.var(min_dist) - np.min(min_dist)) / (np.max(min_dist) - np.min(min_dist))      # :96-97
+        counts = np.zeros(n_a)
+        for c in range(n_g):                                           # :110-121
+            counts[np.argmin(np.linalg.norm(p - grid[:, [c]], axis=0))] += 1
+        m3 = (np.var(counts) - np.min(counts)) / (np.max(counts) - np.min(counts))              # :124-126
+    return np.array([m1, m2, m3])

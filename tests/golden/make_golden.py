@@ -90,6 +90,9 @@ def record_episode(env, n_steps, mode, rng, warm=0):
         if mode == "prior":
             a = ap.astype(np.float32)
     out = {k: np.stack(v) for k, v in rec.items()}
+    # the wrapper's evaluation metrics on the final state (assembly_wrapper.py:48-128)
+    with np.errstate(all="ignore"):
+        out["metrics"] = np.array([env.coverage_rate(), env.distribution_uniformity(), env.voronoi_based_uniformity()])
     out.update(grid=base.grid_center.copy(), l_cell=np.float64(base.l_cell), r_avoid=np.float64(base.r_avoid),
                d_sen=np.float64(base.d_sen), boundary=base.boundary_pos.copy(),
                is_boundary=np.bool_(base.is_boundary), with_self=np.bool_(base.is_con_self_state))
