@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SWARM_ABI_VERSION 1
+#define SWARM_ABI_VERSION 2
 
 enum { SWARM_F32 = 0, SWARM_F64 = 1 };
 
@@ -138,6 +138,13 @@ int  swarm_step(swarm_env_t *h, const void *action, int action_dtype,
  * [coverage_rate, distribution_uniformity, voronoi_based_uniformity] of
  * /root/reference/cus_gym/gym/wrappers/customized_envs/assembly_wrapper.py:48-128 (numpy semantics incl. np.var). */
 int  swarm_metrics(swarm_env_t *h, double *out);
+
+/* The reference's rule-based expert controller (agent_strategy == 'rule', assembly.py:530-601) evaluated on the CURRENT
+ * state: action[E][N][2] (DEVICE pointer, double), clipped to [-1, 1]; feed it to swarm_step with SWARM_F64 to reproduce
+ * a rule-mode step (with is_collected the reference returns it as the fifth element, assembly.py:663-664).  Runs the
+ * observation pass with the index export switched on, then a one-thread-per-agent kernel.  fp64 in numpy's operation
+ * order; np.cos differs from the device cos by a few ulp, so parity is 1e-12 absolute, not bit-exact. */
+int  swarm_rule_action(swarm_env_t *h, double *action);
 
 /* Index scratch of the LAST swarm_observe/swarm_step (device pointers, any may be NULL).  The first
  * call that asks for sensed/occupied indices allocates the export buffers and re-runs the observation

@@ -25,10 +25,11 @@ class SwarmError(RuntimeError):
 
 _LIB = None
 
+ABI_VERSION = 2            # include/swarm_env.h SWARM_ABI_VERSION
 BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", "swarm_destroy", "swarm_last_error",
                    "swarm_set_stream", "swarm_synchronize", "swarm_obs_dim", "swarm_set_cells", "swarm_set_state",
                    "swarm_get_state", "swarm_observe", "swarm_step", "swarm_get_indices",
-                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_metrics")
+                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_metrics", "swarm_rule_action")
 LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior")
 
 
@@ -56,6 +57,7 @@ def load():
     lib.swarm_get_state.argtypes = [vp, vp, vp]; lib.swarm_get_state.restype = i32
     lib.swarm_get_cells.argtypes = [vp, vp, vp]; lib.swarm_get_cells.restype = i32
     lib.swarm_metrics.argtypes = [vp, vp]; lib.swarm_metrics.restype = i32
+    lib.swarm_rule_action.argtypes = [vp, vp]; lib.swarm_rule_action.restype = i32
     lib.swarm_observe.argtypes = [vp, vp]; lib.swarm_observe.restype = i32
     lib.swarm_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]; lib.swarm_step.restype = i32
     lib.swarm_get_indices.argtypes = [vp, vp, vp, vp, vp]; lib.swarm_get_indices.restype = i32
@@ -65,7 +67,7 @@ def load():
     lib.swarm_reset.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp]; lib.swarm_reset.restype = i32
     lib.swarm_timer_start.argtypes = [vp]; lib.swarm_timer_start.restype = i32
     lib.swarm_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]; lib.swarm_timer_stop.restype = i32
-    if lib.swarm_abi_version() != 1:
+    if lib.swarm_abi_version() != ABI_VERSION:
         raise SwarmError("libswarmenv.so ABI version mismatch; rebuild")
     _LIB = lib
     return lib

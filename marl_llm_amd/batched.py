@@ -201,6 +201,13 @@ class SwarmBatch:
         check(self.lib, self.handle, self.lib.swarm_metrics(self.handle, _ptr(out)))
         return out
 
+    def rule_action(self):
+        """[E, N, 2] float64 tensor: the rule-based expert's action for the current state (assembly.py:530-601)."""
+        out = torch.empty((self.n_env, self.n_agents, 2), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_rule_action(self.handle, _ptr(out)))
+        return out
+
     def lattice_envs(self):
         """Number of envs whose target cells were recognised as a lattice subset (fast sensed/occupied path)."""
         return int(self.lib.swarm_lattice_envs(self.handle))

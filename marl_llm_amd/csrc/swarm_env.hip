@@ -1272,6 +1272,93 @@ k_metrics(const KP P, double *__restrict__ out)
     if (tid == 0) out[(size_t)e * 3 + 2] = np_var_metric(val, tmp, N);
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// rule-based expert controller: agent_strategy == 'rule',
+// /root/reference/cus_gym/gym/envs/customized_envs/assembly.py:530-601, for the CURRENT state.  Not a hot path (expert
+// data collection, collect_expert_data.py): one thread per agent, fp64 in numpy's operation order (np.sum's pairwise
+// blocks of 8 included).  It consumes what the observation pass left in HBM: nearest cell / in-shape flag and the
+// capped sensed-cell list (`exp_sensed`, the same filter + round(i*step) selection as :544-572).  np.cos is numpy's
+// vectorised routine, so v_exp agrees to a few ulp, not bit for bit (tests: 1e-12 absolute on the clipped action).
+// -------------------------------------------------------------------------------------------------
+template <class F>
+__device__ double np_sum_stream(int n, F f)      // np.sum of f(0..n-1) for n <= 128, values generated on the fly
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += f(i);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = f(k);
+    const int n8 = n - (n % 8);
+    int i;
+    for (i = 8; i < n8; i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] += f(i + k);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += f(i);
+    return res;
+}
+
+__global__ void __launch_bounds__(256)
+k_rule(const KP P, double *__restrict__ out)     // out [E][N][2]
+{
+    const int N = P.n_a, e = blockIdx.x, G = P.g_max;
+    const double *px = P.p + (size_t)e * 2 * N, *py = px + N;
+    const double *vx = P.dp + (size_t)e * 2 * N, *vy = vx + N;
+    const double *gx = P.cells + (size_t)e * 2 * P.ng_max, *gy = gx + P.ng_max;
+    const double k_1 = 1, k_2 = 15, k_3 = 17;                                  // :532
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const double xi = px[i], yi = py[i], ui = vx[i], wi = vy[i];
+        const bool in_shape = P.in_flag[(size_t)e * N + i] != 0;
+        double ent_x = 0.0, ent_y = 0.0;                                       // :538-541
+        if (!in_shape) {
+            const int bc = P.near_cell[(size_t)e * N + i];
+            const double rx = gx[bc] - xi, ry = gy[bc] - yi;
+            const double nr = sqrt(rx * rx + ry * ry) + 1e-8;
+            ent_x = k_1 * (rx / nr) + (0.0 - ui);
+            ent_y = k_1 * (ry / nr) + (0.0 - wi);
+        }
+        const int *sel = P.exp_sensed + ((size_t)e * N + i) * G;               // capped list, -1 padded (:561-572)
+        int n = 0;
+        while (n < G && sel[n] >= 0) ++n;
+        double exp_x = 0.0, exp_y = 0.0;                                       // :574-584
+        if (n > 0) {
+            auto psi = [&](double rx, double ry) {                             // _rho_cos_dec(z, 0, d_sen) :846-850
+                const double z = sqrt(rx * rx + ry * ry);
+                return z < P.d_sen ? 0.5 * (1.0 + cos(M_PI * (z / P.d_sen - 0) / (1.0 - 0))) : 0.0;
+            };
+            const double sx = np_sum_stream(n, [&](int q) { const int c = sel[q]; const double rx = gx[c] - xi, ry = gy[c] - yi; return psi(rx, ry) * rx; });
+            const double sy = np_sum_stream(n, [&](int q) { const int c = sel[q]; const double rx = gx[c] - xi, ry = gy[c] - yi; return psi(rx, ry) * ry; });
+            double den = np_sum_stream(n, [&](int q) { const int c = sel[q]; return psi(gx[c] - xi, gy[c] - yi); });
+            if (den == 0) den = 1e-8;
+            exp_x = k_2 * sx / den; exp_y = k_2 * sy / den;
+        }
+        int n_near = 0;                                                        // :587-598
+        for (int j = 0; j < N; ++j) {
+            const double rx = px[j] - xi, ry = py[j] - yi;
+            n_near += (j != i && sqrt(rx * rx + ry * ry) < P.d_sen) ? 1 : 0;
+        }
+        double int_x = 0.0, int_y = 0.0;
+        for (int j = 0; j < N; ++j) {
+            const double rx = px[j] - xi, ry = py[j] - yi;
+            const double nr = sqrt(rx * rx + ry * ry);
+            if (j == i || !(nr < P.d_sen)) continue;
+            if (nr < P.r_avoid) {
+                const double c = -k_3 * (P.r_avoid / nr - 1);
+                int_x += c * rx; int_y += c * ry;
+            }
+            int_x += 5 * (vx[j] - ui) / n_near; int_y += 5 * (vy[j] - wi) / n_near;
+        }
+        const double ax = (ent_x + exp_x) + int_x, ay = (ent_y + exp_y) + int_y;
+        out[((size_t)e * N + i) * 2 + 0] = fmin(fmax(ax, -1.0), 1.0);          // np.clip :601
+        out[((size_t)e * N + i) * 2 + 1] = fmin(fmax(ay, -1.0), 1.0);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
@@ -1893,6 +1980,27 @@ int swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flags
     if (neighbor_index) HIP_TRY(h, hipMemcpyAsync(neighbor_index, h->d_nei, EN * (size_t)h->kp.topo * 4, hipMemcpyDefault, h->stream));
     if (in_flags) HIP_TRY(h, hipMemcpyAsync(in_flags, h->d_inflag, EN * 4, hipMemcpyDefault, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWARM_OK;
+}
+
+int swarm_rule_action(swarm_env_t *h, double *action)
+{
+    if (!h || !action) return SWARM_ERR_INVALID;
+    if (!h->observed) return fail(h, SWARM_ERR_STATE, "swarm_rule_action: nothing observed yet");
+    if (h->kp.g_max > 128) return fail(h, SWARM_ERR_INVALID, "swarm_rule_action: num_obs_grid_max > 128 not supported");
+    DeviceGuard g(h->device);
+    const size_t EN = (size_t)h->cfg.n_env * h->cfg.n_agents;
+    if (!h->d_exp_sensed) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_exp_sensed, EN * (size_t)h->kp.g_max * 4));
+        HIP_TRY(h, hipMalloc((void **)&h->d_exp_occ, EN * (size_t)h->kp.occ_max * 4));
+    }
+    // observation pass on the current state with the index export switched on (idempotent, see swarm_get_indices)
+    h->kp.export_idx = 1; h->kp.exp_sensed = h->d_exp_sensed; h->kp.exp_occ = h->d_exp_occ;
+    int rc = launch(h, false, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+    h->kp.export_idx = 0;
+    if (rc != SWARM_OK) return rc;
+    hipLaunchKernelGGL(k_rule, dim3(h->cfg.n_env), dim3(h->cfg.n_agents <= 64 ? 64 : 256), 0, h->stream, h->kp, action);
+    HIP_TRY(h, hipGetLastError());
     return SWARM_OK;
 }
 

@@ -100,10 +100,10 @@ class AssemblySwarmEnv(_EnvBase):
         self.alpha = 1
         if self.dynamics_mode != "Cartesian":
             raise ValueError("only dynamics_mode='Cartesian' exists in the reference (assembly.py:141-146)")
-        if self.agent_strategy != "input":
-            raise NotImplementedError("agent_strategy %r: only 'input' is on the GPU path" % (self.agent_strategy,))
-        if self.is_collected:
-            raise NotImplementedError("is_collected (rule-based expert collection) is not on the GPU path yet")
+        if self.agent_strategy not in ("input", "random", "rule"):
+            # 'llm' drives the agents with the Python twin of the prior (assembly.py:892-940, other constants than the
+            # deployed C++ prior); nothing in marl_llm/ selects it
+            raise NotImplementedError("agent_strategy %r: 'input', 'random' and 'rule' are on the GPU path" % (self.agent_strategy,))
 
         results = args.results_file if isinstance(args.results_file, dict) else load_results(args.results_file)
         self.l_cells = list(results["l_cell"])
@@ -217,7 +217,17 @@ class AssemblySwarmEnv(_EnvBase):
             b.observe()
             self._cells_dirty = False
         self.simulation_time += self.dt
-        return b.step(action)
+        if self.agent_strategy == "rule":          # assembly.py:530-601: the expert controller replaces the passed action
+            action = b.rule_action()
+        elif self.agent_strategy == "random":      # assembly.py:523-524 (numpy's global stream, one draw per step)
+            import torch
+            E, N = self.n_envs, self.n_agents_per_env
+            u = np.random.uniform(-1, 1, (self.act_dim_agent, self.n_a))
+            action = torch.as_tensor(np.ascontiguousarray(u.T.reshape(E, N, 2)), device=b.device)
+        obs, rew, done, pri = b.step(action)
+        if self.is_collected:                      # assembly.py:663-664: the applied action is returned instead of the prior
+            pri = action
+        return obs, rew, done, pri
 
     def step(self, a):
         import torch

@@ -352,3 +352,61 @@ def wrapper_metrics(p, grid, r_avoid):
             counts[np.argmin(np.linalg.norm(p - grid[:, [c]], axis=0))] += 1
         m3 = (np.var(counts) - np.min(counts)) / (np.max(counts) - np.min(counts))              # :124-126
     return np.array([m1, m2, m3])
+
+
+def rule_action(p, dp, grid, l_cell, r_avoid, d_sen=D_SEN, g_max=G_MAX):
+    """The rule-based expert controller, agent_strategy == 'rule' (assembly.py:530-601), restated with the same numpy
+    calls in the same order.  Returns a (2, n_a) clipped to [-1, 1]."""
+    n_a = p.shape[1]
+    a = np.zeros((2, n_a))
+    k_1, k_2, k_3 = 1, 15, 17                                                   # :532
+    for i in range(n_a):
+        rel_pos = grid - p[:, [i]]                                              # _get_trgt_grid_state :828-844
+        rel_pos_norm = np.linalg.norm(rel_pos, axis=0)
+        min_index = np.argmin(rel_pos_norm)
+        if rel_pos_norm[min_index] < np.sqrt(2) * l_cell / 2:
+            in_flag, target_pos, target_vel = 1, p[:, i], dp[:, i]
+        else:
+            in_flag, target_pos, target_vel = 0, grid[:, min_index], np.array([0, 0])
+        sensed_indices = np.where(rel_pos_norm < d_sen)[0]
+        target_pos_rel = target_pos - p[:, i]; target_vel_rel = target_vel - dp[:, i]
+        if in_flag == 1:                                                        # :538-541
+            v_ent = np.zeros(2)
+        else:
+            v_ent = k_1 * (target_pos_rel / (np.linalg.norm(target_pos_rel) + 1e-8)) + target_vel_rel
+        if len(sensed_indices) > 0:                                             # :544-558
+            sensed_grid = grid[:, sensed_indices]
+            if in_flag == 1:
+                agent_pos_rel_norm = np.linalg.norm(p - p[:, [i]], axis=0)
+                for nb in np.where(agent_pos_rel_norm < (d_sen + r_avoid / 2))[0]:
+                    mask = np.where(np.linalg.norm(sensed_grid - p[:, [nb]], axis=0) > r_avoid / 2)[0]
+                    sensed_grid = sensed_grid[:, mask]; sensed_indices = sensed_indices[mask]
+        n_s = len(sensed_indices)                                               # :561-572
+        if n_s > g_max:
+            step = (n_s - 1) / (g_max - 1)
+            final = np.array(sensed_indices)[np.round(np.arange(0, g_max) * step).astype(int)]
+            sensed_grid_pos = grid[:, final]
+        elif n_s > 0:
+            sensed_grid_pos = grid[:, sensed_indices]
+        else:
+            sensed_grid_pos = None
+        v_exp = np.zeros(2)                                                     # :574-584
+        if sensed_grid_pos is not None:
+            rel = sensed_grid_pos - p[:, [i]]
+            z = np.linalg.norm(rel, axis=0)
+            psi = np.where(z < 0 * d_sen, 1.0, np.where(z < d_sen, 0.5 * (1.0 + np.cos(np.pi * (z / d_sen - 0) / (1.0 - 0))), 0.0))
+            num = np.sum(psi * rel, axis=1); den = np.sum(psi)
+            if den == 0:
+                den = 1e-8
+            v_exp += k_2 * num / den
+        agent_pos_rel = p - p[:, [i]]; agent_vel_rel = dp - dp[:, [i]]          # :587-598
+        nrm = np.linalg.norm(agent_pos_rel, axis=0)
+        nearby = np.where(nrm < d_sen)[0]
+        nearby = nearby[nearby != i]
+        v_int = np.zeros(2)
+        for nb in nearby:
+            if nrm[nb] < r_avoid:
+                v_int += -k_3 * (r_avoid / nrm[nb] - 1) * agent_pos_rel[:, nb]
+            v_int += 5 * agent_vel_rel[:, nb] / len(nearby)
+        a[:, i] = np.clip(v_ent + v_exp + v_int, -1, 1)                         # :600-601
+    return a

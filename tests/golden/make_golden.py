@@ -53,9 +53,9 @@ def import_reference_env():
     return gym, AssemblySwarmWrapper
 
 
-def make_env(gym, Wrapper, n_a, pkl, is_boundary=True, with_self=True):
-    args = types.SimpleNamespace(n_a=n_a, render_traj=False, traj_len=15, is_collected=False, video=False,
-                                 is_boundary=is_boundary, dynamics_mode="Cartesian", agent_strategy="input",
+def make_env(gym, Wrapper, n_a, pkl, is_boundary=True, with_self=True, strategy="input", collected=False):
+    args = types.SimpleNamespace(n_a=n_a, render_traj=False, traj_len=15, is_collected=collected, video=False,
+                                 is_boundary=is_boundary, dynamics_mode="Cartesian", agent_strategy=strategy,
                                  is_con_self_state=with_self, is_feature_norm=False, training_method="llm_rl",
                                  results_file=pkl)
     return Wrapper(gym.make("AssemblySwarm-v0").unwrapped, args)
@@ -132,6 +132,24 @@ def main():
         np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
         print(tag, "in_shape", rec["in_flags"].sum(1), "reward", rec["rew"].sum((1, 2)),
               "occupied", (rec["occupied"] >= 0).sum((1, 2)), "sensed max", (rec["sensed"] >= 0).sum(2).max())
+
+    # ---- G5: the rule-based expert (agent_strategy='rule', is_collected=True: step returns u, assembly.py:530-601,663-664)
+    for n_a in (8, 32):
+        np.random.seed(500 + n_a)
+        env = make_env(gym, Wrapper, n_a, pkl, strategy="rule", collected=True)
+        env.reset()
+        b = env.env
+        rec = {k: [] for k in ("p", "dp", "u", "p_next", "dp_next", "rew")}
+        for t in range(40):
+            pre_p, pre_dp = b.p.copy(), b.dp.copy()
+            o, r, d, _, u = env.step(np.zeros((2, n_a), np.float32))          # the passed action is ignored in rule mode
+            if t >= 34:                                                          # keep the last steps (swarm partly assembled)
+                rec["p"].append(pre_p); rec["dp"].append(pre_dp); rec["u"].append(u.copy())
+                rec["p_next"].append(b.p.copy()); rec["dp_next"].append(b.dp.copy()); rec["rew"].append(r.copy())
+        out = {k: np.stack(v) for k, v in rec.items()}
+        out.update(grid=b.grid_center.copy(), l_cell=np.float64(b.l_cell), r_avoid=np.float64(b.r_avoid), d_sen=np.float64(b.d_sen))
+        np.savez_compressed(os.path.join(HERE, f"g5_rule_n{n_a}.npz"), **out)
+        print("g5_rule", n_a, "|u| max", np.abs(out["u"]).max(), "reward", out["rew"].sum((1, 2)))
 
     # ---- G4: reset() draw order under seed 226 (assembly_cfg.py:174 default seed), N = 8
     np.random.seed(226)

@@ -32,7 +32,8 @@ def test_header_symbols_exported(lib):
     assert set(BATCHED_SYMBOLS) | set(LEGACY_SYMBOLS) == set(names), names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/swarm_env.h but not exported"
-    assert lib.swarm_abi_version() == 1
+    from marl_llm_amd._lib import ABI_VERSION
+    assert lib.swarm_abi_version() == ABI_VERSION
 
 
 def test_config_struct_matches_header(lib):

@@ -46,4 +46,4 @@ def test_unsupported_modes_fail_loudly(shapes):
     with pytest.raises(ValueError):
         _env(shapes, dynamics_mode="Polar")
     with pytest.raises(NotImplementedError):
-        _env(shapes, agent_strategy="rule")
+        _env(shapes, agent_strategy="llm")
