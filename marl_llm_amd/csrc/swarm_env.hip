@@ -238,7 +238,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const int tid = threadIdx.x, lane = tid & 63;
     STAMP(0);
     const int at = tid % AG;                 // agent thread
-    const int sx = tid / AG;                 // split (wave-uniform)
+    const int sx = __builtin_amdgcn_readfirstlane(tid / AG);   // split: wave-uniform (AG is a multiple of 64), kept in an SGPR
     const int aw = at >> 6;                  // which 64-agent group of the environment
     const int el = NPAD < 64 ? at / NPAD : 0;
     const int i = NPAD < 64 ? at % NPAD : at;
@@ -562,6 +562,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const bool wave_exact = (P.force_exact != 0) || (__any(lane_far) != 0);
     float best32 = INFINITY, second32 = INFINITY; int bc = 0;
     const f2v pxx = {pxf, pxf}, pyy = {pyf, pyf};
+    float lat_dlt = 0.0f, lat_l2 = 1.0f;
     if (use_lat) {
         // ---- lattice path.  Row b of the lattice holds the cells of columns rowmask[b]; the columns within
         // lattice distance rho of the agent form an interval.  Columns inside the radius shrunk by 0.01 steps are
@@ -633,31 +634,44 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             for (int t = sx; t < 2 * P.lat_rw + 2; t += WPE) row_run(b0s + t, L.R, P.c_sen, P.csen_lo, P.csen_hi, sbits, false);
             const int b0c = (int)floorf(bpf) - P.lat_cw;
             for (int t = sx; t < 2 * P.lat_cw + 2; t += WPE) row_run(b0c + t, L.Rc, P.c_occ, P.cocc_lo, P.cocc_hi, cov + el * (P.ngw + 1), true);
-            // nearest cell: value / index tracking only (fp32 with ambiguity detection, as in the generic scan)
+            // nearest cell (CPP:858-908) from the lattice too: in row b the nearest cell is the set column closest to
+            // the agent's column coordinate, on either side of it -- two candidates per row, rows dealt over the splits.
+            // best / runner-up are tracked in lattice units; a runner-up within the model's error of the best sends the
+            // lane to the exact scan below (cells further out on the same side of a row are >= 1 step^2 worse than that
+            // side's candidate, so they are never a runner-up within tolerance).
             best32 = INFINITY; second32 = INFINITY; bc = 0;
-            for (int w = 0; w < W; ++w) {
-                if (!mine(w)) continue;
-                int bl = 0; const float best_in = best32;
-                const float4 *cq = reinterpret_cast<const float4 *>(cq_e + w * 64);
-                static_for<16>([&](auto prc) {
-                    constexpr int pr = decltype(prc)::value;
-                    const float4 q = cq[pr];
-                    const f2v gx = {q.x, q.y}, gy = {q.z, q.w};
-                    const f2v rx = gx - pxx, ry = gy - pyy;
-                    const f2v d2v = __builtin_elementwise_fma(rx, rx, ry * ry);
-                    static_for<2>([&](auto hc) {
-                        constexpr int hh = decltype(hc)::value;
-                        constexpr int b = 2 * pr + hh;
-                        const float d2 = hh ? d2v.y : d2v.x;
-                        second32 = __builtin_amdgcn_fmed3f(best32, second32, d2);
-                        const bool lt = d2 < best32;
-                        best32 = lt ? d2 : best32;
-                        bl = lt ? b : bl;
-                    });
-                });
-                if (best32 < best_in) bc = w * 32 + bl;
+            {
+                // split the row at the agent's column: `dn` = set columns left of it, `up` = right of it; the nearest
+                // of each side is that side's only possible best or runner-up
+                const int ar0 = (int)floorf(apf) + 1;
+                const int a_r = ar0 < 0 ? 0 : (ar0 > 63 ? 63 : ar0);
+                const u64 lowm = (1ull << a_r) - 1ull;                       // columns < a_r
+                const int nr_hi = EPB == 1 ? nrows : 64;
+                for (int b = sx; b < nr_hi; b += WPE) {
+                    const u64 rowm = (EPB == 1 || b < nrows) ? rm[b] : 0ull;
+                    const int rst = rs[b];
+                    const float dy = (float)b - bpf, dy2 = dy * dy;
+                    const u64 up = rowm >> a_r, dn = rowm & lowm;
+                    const int below_cnt = __popcll(dn);
+                    const int a_up = a_r + __ffsll((unsigned long long)up) - 1;
+                    const int a_dn = 63 - __clzll((long long)dn);
+                    const float dxu = (float)a_up - apf, dxd = (float)a_dn - apf;
+                    const float d2u = (act && up != 0) ? fmaf(dxu, dxu, dy2) : INFINITY;
+                    const float d2d = (act && dn != 0) ? fmaf(dxd, dxd, dy2) : INFINITY;
+                    // lower cell index first: on an exact tie the strict compare keeps it (and the tie is re-done exactly)
+                    second32 = __builtin_amdgcn_fmed3f(best32, second32, d2d);
+                    bool lt = d2d < best32;
+                    best32 = lt ? d2d : best32; bc = lt ? rst + below_cnt - 1 : bc;
+                    second32 = __builtin_amdgcn_fmed3f(best32, second32, d2u);
+                    lt = d2u < best32;
+                    best32 = lt ? d2u : best32; bc = lt ? rst + below_cnt : bc;
+                }
             }
         }
+        // from lattice units to the fp32-copy units of the exact re-scan below, with the model's error bound:
+        // |coordinate error| <= 2^-23 max(|a|, |b|) (fp32 cast) + 1e-6 (lattice fit tolerance) steps
+        lat_dlt = 1.2e-7f * fmaxf(fabsf(apf), fabsf(bpf)) + 2e-6f;
+        lat_l2 = (float)(P.d_sen / (double)L.R); lat_l2 *= lat_l2;
     } else
     for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
     FENCE();
@@ -722,13 +736,21 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     }
     {   // nearest cell of this split: unambiguous in fp32 unless the runner-up is within tolerance
-        const float tol = P.min_tol_a * sqrtf(second32) + P.min_tol_b * second32 + 1e-9f;
+        float tol, thr_amb;
+        if (use_lat) {      // lattice units; the re-scan threshold converted to real units, widened for the fp32 copy
+            tol = 6.0f * sqrtf(second32) * lat_dlt + 1e-9f;
+            const float t = (best32 + tol) * lat_l2 * 1.0001f;
+            thr_amb = t + P.min_tol_a * sqrtf(t) + P.min_tol_b * t + 1e-9f;
+        } else {
+            tol = P.min_tol_a * sqrtf(second32) + P.min_tol_b * second32 + 1e-9f;
+            thr_amb = best32 + tol;
+        }
         const bool unc_min = act && (wave_exact || (second32 < INFINITY && (second32 - best32) <= tol));
         if (__any(unc_min)) {
-            const float thr = unc_min ? (wave_exact ? INFINITY : best32 + tol) : -1.0f;
+            const float thr = unc_min ? (wave_exact ? INFINITY : thr_amb) : -1.0f;
             double bestd = INFINITY; int bcd = bc;
             for (int w = 0; w < W; ++w) {
-                if (!mine(w)) continue;
+                if (!use_lat && !mine(w)) continue;          // lattice: rows, not words, were dealt out -- scan them all
                 for (int b = 0; b < 32; ++b) {
                     const int cc = w * 32 + b;
                     const float rx = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf, ry = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf;
@@ -1053,7 +1075,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             // wave per row: lane = slot, so the row's agent position, cell base and output base are wave-uniform
             // and each store instruction covers 64 consecutive pairs (512 B / 1 KiB contiguous).  CPP:274-291
             const int Gp = P.g_max;
-            const int wv = tid >> 6, nwv = T >> 6;
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
             const int nfull = Gp >> 6, tail = Gp & 63;
             for (int r = wv; r < rows; r += nwv) {
                 const int elr = EPB > 1 ? r / n_a : 0;

@@ -260,6 +260,21 @@ def _adversarial_case(rng, shapes, n_a, ra, d_sen=0.4):
             p[:, i] = g[:, c] + u * (np.sqrt(2) * l_cell / 2) * (1 + e)
         elif mode == 4 and i > 0:
             p[:, i] = p[:, i - 1] + u * [d_sen, ra, 0.07, d_sen + ra / 2][k % 4] * (1 + e)
+        elif mode == 5:
+            # nearest-cell ties across lattice rows: the midpoint of two vertically adjacent cells, the common vertex
+            # of a 2x2 block (four-way tie -> lowest index wins), and the same from far outside the shape
+            dd = np.linalg.norm(g - g[:, [c]], axis=0)
+            nb = np.where((dd > 0) & (dd < 1.01 * l_cell))[0]
+            if len(nb):
+                d = g[:, nb[int(rng.integers(0, len(nb)))]] - g[:, c]
+                perp = np.array([-d[1], d[0]])
+                sub = k % 3
+                if sub == 0:
+                    p[:, i] = g[:, c] + 0.5 * d + d * e
+                elif sub == 1:
+                    p[:, i] = g[:, c] + 0.5 * d + 0.5 * perp + u * abs(e)
+                else:
+                    p[:, i] = g[:, c] + 0.5 * d + perp * (rng.integers(3, 12) + 0.5) + d * e
     return np.ascontiguousarray(p), dp, g, l_cell
 
 
