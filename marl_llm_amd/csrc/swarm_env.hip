@@ -79,6 +79,7 @@ struct KP {
     int off_cxyf, off_partc, off_lat, off_cov, off_flag;
     int lattice;               // every env's cells are a lattice subset: row-run path for sensed / occupied bits
     int lat_rw, lat_cw;        // row half-windows (lattice steps) for d_sen and r_avoid/2
+    int lat_n32;               // every env's lattice has <= 32 columns: 32-bit row masks
     double c_near_hi;          // c_near * (1 + 1e-9): pairs in [c_near, c_near_hi) flag the exact occupied-cell path
     const LatEnv *lat;
     double d_sen, r_avoid, size_a, size2, k_ball, k_wall, c_wall, vel_max, dt;
@@ -238,7 +239,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const int tid = threadIdx.x, lane = tid & 63;
     STAMP(0);
     const int at = tid % AG;                 // agent thread
-    const int sx = __builtin_amdgcn_readfirstlane(tid / AG);   // split: wave-uniform (AG is a multiple of 64), kept in an SGPR
+    // split: wave-uniform (AG is a multiple of 64), kept in an SGPR.  The roles rotate with the workgroup index: the
+    // k-th wave of every workgroup lands on the same SIMD, and splits A / B carry extra sequential work (forces, prior,
+    // ordered insertion, reward combine) -- rotating spreads that over the four SIMDs of a CU.
+    const int sx = __builtin_amdgcn_readfirstlane((tid / AG + (int)blockIdx.x) % WPE);
     const int aw = at >> 6;                  // which 64-agent group of the environment
     const int el = NPAD < 64 ? at / NPAD : 0;
     const int i = NPAD < 64 ? at % NPAD : at;
@@ -565,41 +569,53 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     float lat_dlt = 0.0f, lat_l2 = 1.0f;
     if (use_lat) {
         // ---- lattice path.  Row b of the lattice holds the cells of columns rowmask[b]; the columns within
-        // lattice distance rho of the agent form an interval.  Columns inside the radius shrunk by 0.01 steps are
-        // in range for certain (model error ~1e-7 steps), columns outside the radius grown by 0.01 are not; the
-        // (at most a few) columns in between are decided by the reference's exact fp64 test on the stored
-        // coordinates.  Selected cells of a row are consecutive cell indices: one run OR-ed into the bit set.
+        // lattice distance rho of the agent form an interval.  Columns inside the radius shrunk by the margin lat_m
+        // are in range for certain, columns outside the radius grown by lat_m are not; the (rare) columns in between
+        // are decided by the reference's exact fp64 test on the stored coordinates.  lat_m = 5x the model's error
+        // bound: per coordinate 2^-24 |coordinate| (fp32 cast of the fp64 lattice coordinate) + 1e-6 (lattice fit
+        // tolerance of detect_lattice) + ~1e-6 (fp32 radius / sqrt roundings), i.e. < 2e-5 steps for |coordinate| <= 128.
+        // Selected cells of a row are consecutive cell indices: one run OR-ed into the bit set.
         const LatEnv &L = P.lat[es];
         const float apf = (float)((px - L.ox) * L.uxi + (py - L.oy) * L.uyi);
         const float bpf = (float)((px - L.ox) * L.vxi + (py - L.oy) * L.vyi);
         const int nrows = L.nrows, ncols = L.ncols;
+        const float lat_m = fmaxf(1e-4f, 8e-7f * fmaxf(fabsf(apf), fabsf(bpf)));
         const u64 *rm = lrm + el * 64;
         const short *rs = lrs + el * 64;
+        // The walk is instantiated for 32-bit row masks (every env's lattice has <= 32 columns: the reference's shapes
+        // do) and for 64-bit ones.
+        auto walk = [&](auto tag) {
+        typedef decltype(tag) MT;
+        constexpr int MB = (int)sizeof(MT) * 8;
+        auto rowmask = [&](int b) -> MT { return MB == 32 ? (MT)reinterpret_cast<const unsigned *>(rm)[2 * b] : (MT)rm[b]; };
+        auto popc = [](MT v) -> int { return MB == 32 ? __popc((unsigned)v) : __popcll((unsigned long long)v); };
+        auto ffs0 = [](MT v) -> int { return (MB == 32 ? __ffs((unsigned)v) : __ffsll((unsigned long long)v)) - 1; };
+        // columns lo..hi inclusive, 0 <= lo, hi <= MB-1; empty when hi < lo
+        auto range = [](int lo, int hi) -> MT { return hi >= lo ? (MT)((~(MT)0 >> (MB - 1 - hi)) & (~(MT)0 << lo)) : (MT)0; };
         auto row_run = [&](int b, float rho, double cut, float cut_lo, float cut_hi, unsigned *dst, bool dst_shared) {
             // columns of row b within lattice distance rho of (apf, bpf); exact test d2 < cut on the boundary columns
             const bool rowok = act && b >= 0 && b < nrows;
             const float dy = (float)b - bpf;
-            const float ro = rho + 0.01f, ri = rho - 0.01f;
+            const float ro = rho + lat_m, ri = rho - lat_m;
             const float ho2 = ro * ro - dy * dy, hi2 = ri * ri - dy * dy;
             const bool any_o = rowok && ho2 > 0.0f;
-            const float ho = __builtin_sqrtf(ho2 > 0.0f ? ho2 : 0.0f);
+            // raw v_sqrt_f32 (1 ulp): its error is far inside the margin
+            const float ho = __builtin_amdgcn_sqrtf(fmaxf(ho2, 0.0f)), hi = __builtin_amdgcn_sqrtf(fmaxf(hi2, 0.0f));
             int ao0 = (int)ceilf(apf - ho), ao1 = (int)floorf(apf + ho);
-            int ai0, ai1;
-            if (hi2 > 0.0f) { const float hi = __builtin_sqrtf(hi2); ai0 = (int)ceilf(apf - hi); ai1 = (int)floorf(apf + hi); }
-            else { ai0 = ao1 + 1; ai1 = ao1; }                               // no certain column in this row
+            int ai0 = (int)ceilf(apf - hi), ai1 = (int)floorf(apf + hi);
+            if (!(hi2 > 0.0f)) { ai0 = ao1 + 1; ai1 = ao1; }                 // no certain column in this row
             ao0 = ao0 < 0 ? 0 : ao0; ao1 = ao1 > ncols - 1 ? ncols - 1 : ao1;
             ai0 = ai0 < ao0 ? ao0 : ai0; ai1 = ai1 > ao1 ? ao1 : ai1;
-            const u64 rowm = any_o ? rm[b < 0 ? 0 : (b > 63 ? 63 : b)] : 0;
-            const int rst = rs[b < 0 ? 0 : (b > 63 ? 63 : b)];
-            auto below = [](int a) -> u64 { return a <= 0 ? 0ull : (a >= 64 ? ~0ull : ((1ull << a) - 1ull)); };
-            u64 acc = (ai1 >= ai0) ? (below(ai1 + 1) & ~below(ai0)) : 0ull;   // certain columns
-            // boundary columns: [ao0, ai0) and (ai1, ao1]
-            u64 bnd = (ao1 >= ao0 ? (below(ao1 + 1) & ~below(ao0)) : 0ull) & ~acc & rowm;
+            const int bq = b < 0 ? 0 : (b > 63 ? 63 : b);
+            const MT rowm = any_o ? rowmask(bq) : (MT)0;
+            const int rst = rs[bq];
+            MT acc = range(ai0, ai1);                                        // certain columns
+            MT bnd = range(ao0, ao1) & ~acc & rowm;                          // boundary columns: [ao0, ai0) and (ai1, ao1]
             while (__any(bnd != 0)) {
                 if (bnd != 0) {
-                    const int a = __ffsll((unsigned long long)bnd) - 1;
+                    const int a = ffs0(bnd);
                     bnd &= bnd - 1;
-                    const int c = rst + __popcll(rowm & below(a));
+                    const int c = rst + popc(rowm & (MT)(((MT)1 << a) - 1));
                     // fp32 copy first (LDS); the exact fp64 test (global) only inside the fp32 guard band
                     const float fx = cq_e[(c >> 1) * 4 + (c & 1)] - pxf, fy = cq_e[(c >> 1) * 4 + 2 + (c & 1)] - pyf;
                     const float d2f = fmaf(fx, fx, fy * fy);
@@ -609,22 +625,30 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         const double ex = g.x - px, ey = g.y - py;
                         in = ex * ex + ey * ey < cut;
                     }
-                    if (in) acc |= 1ull << a;
+                    if (in) acc |= (MT)1 << a;
                 }
             }
-            const u64 sel = rowm & acc;
+            const MT sel = rowm & acc;
             if (sel != 0) {
-                const int a0 = __ffsll((unsigned long long)sel) - 1;
-                const int idx0 = rst + __popcll(rowm & below(a0));
-                const int cnt = __popcll(sel);
-                // bits [idx0, idx0 + cnt): cnt <= 64, may straddle up to three 32-bit words
-                int pos = idx0, left = cnt;
-                while (left > 0) {
-                    const int wq = pos >> 5, off = pos & 31;
-                    const int take = left < 32 - off ? left : 32 - off;
-                    const unsigned m = (take >= 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << off;
-                    atomicOr(dst_shared ? &dst[wq] : &dst[wq * AG + at], m);
-                    pos += take; left -= take;
+                const int a0 = ffs0(sel);
+                const int idx0 = rst + popc(rowm & (MT)(((MT)1 << a0) - 1));
+                const int cnt = popc(sel);
+                // bits [idx0, idx0 + cnt) of the cell-index bit set
+                if constexpr (MB == 32) {                                    // cnt <= 32: at most two words
+                    const int wq = idx0 >> 5, off = idx0 & 31;
+                    const unsigned ones = cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
+                    const unsigned m_lo = ones << off, m_hi = off ? ones >> (32 - off) : 0u;
+                    atomicOr(dst_shared ? &dst[wq] : &dst[wq * AG + at], m_lo);
+                    if (m_hi) atomicOr(dst_shared ? &dst[wq + 1] : &dst[(wq + 1) * AG + at], m_hi);
+                } else {                                                     // cnt <= 64: up to three words
+                    int pos = idx0, left = cnt;
+                    while (left > 0) {
+                        const int wq = pos >> 5, off = pos & 31;
+                        const int take = left < 32 - off ? left : 32 - off;
+                        const unsigned m = (take >= 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << off;
+                        atomicOr(dst_shared ? &dst[wq] : &dst[wq * AG + at], m);
+                        pos += take; left -= take;
+                    }
                 }
             }
         };
@@ -644,17 +668,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 // split the row at the agent's column: `dn` = set columns left of it, `up` = right of it; the nearest
                 // of each side is that side's only possible best or runner-up
                 const int ar0 = (int)floorf(apf) + 1;
-                const int a_r = ar0 < 0 ? 0 : (ar0 > 63 ? 63 : ar0);
-                const u64 lowm = (1ull << a_r) - 1ull;                       // columns < a_r
+                const int a_r = ar0 < 0 ? 0 : (ar0 > MB - 1 ? MB - 1 : ar0);
+                const MT lowm = (MT)(((MT)1 << a_r) - 1);                    // columns < a_r
                 const int nr_hi = EPB == 1 ? nrows : 64;
                 for (int b = sx; b < nr_hi; b += WPE) {
-                    const u64 rowm = (EPB == 1 || b < nrows) ? rm[b] : 0ull;
+                    const MT rowm = (EPB == 1 || b < nrows) ? rowmask(b) : (MT)0;
                     const int rst = rs[b];
                     const float dy = (float)b - bpf, dy2 = dy * dy;
-                    const u64 up = rowm >> a_r, dn = rowm & lowm;
-                    const int below_cnt = __popcll(dn);
-                    const int a_up = a_r + __ffsll((unsigned long long)up) - 1;
-                    const int a_dn = 63 - __clzll((long long)dn);
+                    const MT up = rowm >> a_r, dn = rowm & lowm;
+                    const int below_cnt = popc(dn);
+                    const int a_up = a_r + ffs0(up);
+                    const int a_dn = MB - 1 - (MB == 32 ? __clz((int)dn) : __clzll((long long)dn));
                     const float dxu = (float)a_up - apf, dxd = (float)a_dn - apf;
                     const float d2u = (act && up != 0) ? fmaf(dxu, dxu, dy2) : INFINITY;
                     const float d2d = (act && dn != 0) ? fmaf(dxd, dxd, dy2) : INFINITY;
@@ -668,10 +692,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 }
             }
         }
+        };
+        if (P.lat_n32) walk(0u); else walk((u64)0);
         // from lattice units to the fp32-copy units of the exact re-scan below, with the model's error bound:
         // |coordinate error| <= 2^-23 max(|a|, |b|) (fp32 cast) + 1e-6 (lattice fit tolerance) steps
         lat_dlt = 1.2e-7f * fmaxf(fabsf(apf), fabsf(bpf)) + 2e-6f;
-        lat_l2 = (float)(P.d_sen / (double)L.R); lat_l2 *= lat_l2;
+        lat_l2 = (float)P.d_sen * __builtin_amdgcn_rcpf(L.R); lat_l2 *= lat_l2;    // (cell size)^2; 1 ulp is inside the 1.0001 factor
     } else
     for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
     FENCE();
@@ -876,6 +902,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int w = sx; w <= W; w += WPE) rsel[w * AG + at] = 0;
         __syncthreads();
     }
+    // The cap is rare (an agent deep inside a fine-celled shape): when no agent of this wave is capped -- the same
+    // answer in all WPE splits, they hold the same agents -- ranks are slots and the rank-select bits are skipped.
+    const bool any_sub = __any(n_kept > G) != 0;
+    if (any_sub)
     for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
         FENCE();
         const bool sub = n_kept > G;
@@ -903,6 +933,25 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int rep = 0, reps = REPS(11); rep < reps; ++rep) {
         FENCE();
         int prefix = 0, sbase = 0;
+        if (!any_sub) {
+            for (int w = 0; w < W; ++w) {
+                if (mine(w)) {
+                    unsigned it = sbits[w * AG + at];
+                    int s = prefix;
+                    while (it) {                                   // up to 4 kept bits per trip
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool has = it != 0;
+                            const int b = has ? __ffs(it) - 1 : 0;
+                            it &= it - 1;                          // 0 stays 0
+                            if (has) row[s] = (short)(w * 32 + b);
+                            s += has ? 1 : 0;
+                        }
+                    }
+                }
+                prefix += pc[w * AG + at];
+            }
+        } else
         for (int w = 0; w < W; ++w) {
             const int cnt = pc[w * AG + at];
             unsigned bits = 0;
@@ -1428,9 +1477,10 @@ struct swarm_env {
     double *d_shape_cells, *d_shape_l, *d_shape_cin;
     int *d_shape_ng;
     LatEnv *d_shape_lat;
-    bool shapes_lattice; float shapes_rmax, shapes_cmax;
+    bool shapes_lattice; float shapes_rmax, shapes_cmax; int shapes_ncols;
     std::vector<char> lat_ok;      // per env: cells are a lattice subset
     std::vector<float> lat_R, lat_Rc;
+    std::vector<int> lat_ncols;
     bool lattice_disabled;
     int *d_nei, *d_near, *d_inflag, *d_ng, *d_exp_sensed, *d_exp_occ;
 };
@@ -1673,9 +1723,10 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr;
     h->d_lat = nullptr;
     h->n_shapes = 0; h->d_shape_cells = h->d_shape_l = h->d_shape_cin = nullptr; h->d_shape_ng = nullptr; h->d_shape_lat = nullptr;
-    h->shapes_lattice = false; h->shapes_rmax = h->shapes_cmax = 0.0f;
+    h->shapes_lattice = false; h->shapes_rmax = h->shapes_cmax = 0.0f; h->shapes_ncols = 0;
     h->lat_ok.assign((size_t)cfg->n_env, 0);
     h->lat_R.assign((size_t)cfg->n_env, 0.0f); h->lat_Rc.assign((size_t)cfg->n_env, 0.0f);
+    h->lat_ncols.assign((size_t)cfg->n_env, 0);
     h->lattice_disabled = (cfg->debug_flags & 2) != 0;
     h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr;
     h->cells_set.assign((size_t)cfg->n_env, 0);
@@ -1761,7 +1812,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     }
     k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag;
     k.cells = h->d_cells; k.n_g = h->d_ng; k.c_in = h->d_cin;
-    k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0;
+    k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_n32 = 0;
     k.c_near_hi = k.c_near * (1.0 + 1e-9);
     *out = h;
     return SWARM_OK;
@@ -1832,15 +1883,18 @@ int swarm_set_cells(swarm_env_t *h, int env_begin, int count, const double *cell
                 const double l = L.R;
                 L.R = (float)(h->kp.d_sen / l); L.Rc = (float)((h->kp.r_avoid / 2.0) / l);
                 h->lat_R[(size_t)(env_begin + k)] = L.R; h->lat_Rc[(size_t)(env_begin + k)] = L.Rc;
+                h->lat_ncols[(size_t)(env_begin + k)] = L.ncols;
             }
         }
         HIP_TRY(h, hipMemcpy(h->d_lat + env_begin, lat.data(), (size_t)count * sizeof(LatEnv), hipMemcpyHostToDevice));
-        bool all = true; float rmax = 0.0f, cmax = 0.0f;
+        bool all = true; float rmax = 0.0f, cmax = 0.0f; int ncmax = 0;
         for (int e2 = 0; e2 < h->cfg.n_env; ++e2) {
             if (!h->lat_ok[(size_t)e2]) { all = false; break; }
             rmax = std::max(rmax, h->lat_R[(size_t)e2]); cmax = std::max(cmax, h->lat_Rc[(size_t)e2]);
+            ncmax = std::max(ncmax, h->lat_ncols[(size_t)e2]);
         }
         h->kp.lattice = all ? 1 : 0;
+        h->kp.lat_n32 = ncmax <= 32 ? 1 : 0;
         h->kp.lat_rw = (int)std::ceil(rmax + 0.02f);
         h->kp.lat_cw = (int)std::ceil(cmax + 0.02f);
         if (h->kp.lat_rw > 30) h->kp.lattice = 0;           // sensing radius of > 30 cells: not worth a row walk
@@ -1859,7 +1913,7 @@ int swarm_set_shapes(swarm_env_t *h, int n_shapes, const double *shape_cells, co
     const size_t row = (size_t)2 * h->kp.ng_max;
     std::vector<double> cin((size_t)n_shapes);
     std::vector<LatEnv> lat((size_t)n_shapes);
-    bool all = true; float rmax = 0.0f, cmax = 0.0f;
+    bool all = true; float rmax = 0.0f, cmax = 0.0f; int ncmax = 0;
     for (int k = 0; k < n_shapes; ++k) {
         if (n_g[k] < 1 || n_g[k] > h->cfg.n_cells_max) return fail(h, SWARM_ERR_INVALID, "swarm_set_shapes: n_g must be in [1, n_cells_max]");
         if (!(l_cell[k] > 0)) return fail(h, SWARM_ERR_INVALID, "swarm_set_shapes: l_cell must be positive");
@@ -1870,7 +1924,7 @@ int swarm_set_shapes(swarm_env_t *h, int n_shapes, const double *shape_cells, co
         if (!h->lattice_disabled && detect_lattice(gx, gy, n_g[k], L)) {
             const double l = L.R;
             L.R = (float)(h->kp.d_sen / l); L.Rc = (float)((h->kp.r_avoid / 2.0) / l);
-            rmax = std::max(rmax, L.R); cmax = std::max(cmax, L.Rc);
+            rmax = std::max(rmax, L.R); cmax = std::max(cmax, L.Rc); ncmax = std::max(ncmax, L.ncols);
         } else { std::memset(&L, 0, sizeof(L)); all = false; }
     }
     DeviceGuard g(h->device);
@@ -1886,7 +1940,7 @@ int swarm_set_shapes(swarm_env_t *h, int n_shapes, const double *shape_cells, co
     HIP_TRY(h, hipMemcpy(h->d_shape_cin, cin.data(), (size_t)n_shapes * 8, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_shape_ng, n_g, (size_t)n_shapes * 4, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_shape_lat, lat.data(), (size_t)n_shapes * sizeof(LatEnv), hipMemcpyHostToDevice));
-    h->n_shapes = n_shapes; h->shapes_lattice = all; h->shapes_rmax = rmax; h->shapes_cmax = cmax;
+    h->n_shapes = n_shapes; h->shapes_lattice = all; h->shapes_rmax = rmax; h->shapes_cmax = cmax; h->shapes_ncols = ncmax;
     return SWARM_OK;
 }
 
@@ -1903,10 +1957,14 @@ int swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_off
     HIP_TRY(h, hipGetLastError());
     std::fill(h->cells_set.begin(), h->cells_set.end(), 1);
     std::fill(h->lat_ok.begin(), h->lat_ok.end(), h->shapes_lattice ? 1 : 0);
+    // per-env bounds for a later partial swarm_set_cells: the shape set's maxima are valid for every env
+    std::fill(h->lat_R.begin(), h->lat_R.end(), h->shapes_rmax); std::fill(h->lat_Rc.begin(), h->lat_Rc.end(), h->shapes_cmax);
+    std::fill(h->lat_ncols.begin(), h->lat_ncols.end(), h->shapes_ncols);
     h->have_cells = h->have_state = true;
     h->kp.lattice = h->shapes_lattice ? 1 : 0;
     h->kp.lat_rw = (int)std::ceil(h->shapes_rmax + 0.02f);
     h->kp.lat_cw = (int)std::ceil(h->shapes_cmax + 0.02f);
+    h->kp.lat_n32 = h->shapes_ncols <= 32 ? 1 : 0;
     if (h->kp.lat_rw > 30) h->kp.lattice = 0;
     h->observed = false;
     return swarm_observe(h, obs);

@@ -397,3 +397,53 @@ def test_non_lattice_cells_fall_back_to_generic_path(oracle, shapes):
         for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
             assert np.array_equal(idx[k][e].cpu().numpy(), o[k]), (e, k)
     sb.close()
+
+
+@pytest.mark.parametrize("n_a", [64, 24])
+def test_wide_lattice_uses_64_bit_row_masks(oracle, n_a):
+    """A shape wider than 32 lattice columns (the reference's are not) takes the 64-bit row-mask instantiation of the
+    lattice walk: observation, index scratch and a step against the oracle, including agents on the decision thresholds."""
+    rng = np.random.default_rng(9 + n_a)
+    l_cell, ra = 0.055, 0.12
+    cols, rows = 44, 12
+    keep = rng.uniform(size=(rows, cols)) > 0.12                       # holes; every row keeps some cells
+    keep[:, 0] = True; keep[:, -1] = True
+    bb, aa = np.nonzero(keep)                                          # row-major: rows ascending, columns ascending
+    base = np.stack([aa * l_cell, bb * l_cell]).astype(np.float64)
+    n_env = 6
+    cases = []
+    for e in range(n_env):
+        th = rng.uniform(-np.pi, np.pi)
+        rot = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+        g = np.ascontiguousarray(rot @ (base - base.mean(1, keepdims=True)) + rng.uniform(-0.8, 0.8, (2, 1)))
+        p = g[:, rng.integers(0, g.shape[1], n_a)] + rng.normal(0, 0.05, (2, n_a))
+        for i in range(0, n_a, 3):                                     # threshold cases: d_sen, r_avoid/2, midpoints
+            c = int(rng.integers(0, g.shape[1])); u = rng.normal(size=2); u /= np.linalg.norm(u)
+            p[:, i] = g[:, c] + u * [0.4, ra / 2, 0.5 * l_cell][i % 3] * (1 + [0.0, 1e-13, -1e-10][(i // 3) % 3])
+        dp = rng.uniform(-0.3, 0.3, (2, n_a))
+        cases.append((np.ascontiguousarray(p), dp, g))
+    ng = cases[0][2].shape[1]
+    cells, n_g = _pad_cells([c[2] for c in cases], ng)
+    sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=ng, r_avoid=ra, obs_dtype=torch.float64)
+    sb.set_cells(cells, n_g, [l_cell] * n_env)
+    assert sb.lattice_envs() == n_env
+    sb.set_state(np.stack([c[0] for c in cases]), np.stack([c[1] for c in cases]))
+    obs0 = sb.observe().cpu().numpy()
+    idx = sb.indices()
+    nei = []
+    for e, (pe, dpe, g) in enumerate(cases):
+        o = oracle.get_observation(pe, dpe, g, l_cell, ra)
+        for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+            assert np.array_equal(idx[k][e].cpu().numpy(), o[k]), (e, k)
+        assert np.array_equal(obs0[e], _to_rows(o["obs"])), e
+        nei.append(o["neighbor_index"])
+    act = rng.uniform(-1, 1, (n_env, n_a, 2)).astype(np.float32)
+    obs, rew, done, pri = sb.step(torch.from_numpy(act).to(sb.device))
+    idx = sb.indices()
+    for e, (pe, dpe, g) in enumerate(cases):
+        s = oracle.step(pe, dpe, np.ascontiguousarray(act[e].T.astype(np.float64)), g, nei[e], l_cell, ra)
+        assert np.array_equal(obs[e].cpu().numpy(), _to_rows(s["obs"]))
+        assert np.array_equal(rew[e].cpu().numpy().astype(np.float64), s["reward"][0])
+        for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
+            assert np.array_equal(idx[k][e].cpu().numpy(), s[k]), (e, k)
+    sb.close()
