@@ -64,13 +64,13 @@ struct KP {
     int cxq_stride;            // floats per env in the fp32 pair layout
     int g_stride;              // int16 elements per agent row in LDS
     int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear, off_pc;
-    int smem_bytes, smem_bytes_export;
+    int smem_lat, smem_lat_export, smem_generic;   // dynamic LDS bytes by launch kind
     double c_sen, c_near, c_occ, c_avoid, c_ball;     // squared-distance cut-offs
     // fp32 pre-filter bands: d2_32 < *_lo  =>  exact test true;  d2_32 >= *_hi  =>  exact test false
     float csen_lo, csen_hi, cocc_lo, cocc_hi;
     float coord_lim;           // |coordinate| bound the bands were derived for
     float min_tol_a, min_tol_b;   // nearest-cell ambiguity tolerance: a*sqrt(d2) + b*d2
-    float rew_guard;           // |v| band around 0.05 inside which the reward is re-evaluated in fp64
+    float rew_ga, rew_gb;      // the reward is re-evaluated in fp64 when | |v| - 0.05 | <= rew_ga * n / den + rew_gb
     int force_exact;           // debug: take every exact fallback path
     int cap_int;               // G-1 odd: the cap's round(i*step) is an exact integer division by 2(G-1)
     unsigned cap_magic; int cap_shift;
@@ -161,6 +161,12 @@ template <int NPAD> struct Geo {
     static constexpr int NW = AG / 64;
     static constexpr int WPE = NPAD <= 64 ? 4 : 2;
     static constexpr int T = AG * WPE;
+#ifndef SWARM_WPS
+#define SWARM_WPS 6
+#endif
+    // waves per SIMD the register allocation aims for: six 4-wave workgroups per CU for N <= 64 (26.6 KB of LDS each in
+    // lattice mode); the N > 64 instantiations would spill at that budget
+    static constexpr int WPS = NPAD <= 64 ? SWARM_WPS : 1;
 };
 
 constexpr double kSentinel = 1.0e200;     // coordinates of padding cells: d2 overflows to +inf
@@ -205,7 +211,7 @@ __device__ __forceinline__ float psi_u_f32(float u)
 }
 
 template <int NPAD, typename OT, bool DO_STEP>
-__global__ void __launch_bounds__(Geo<NPAD>::T)
+__global__ void __launch_bounds__(Geo<NPAD>::T, Geo<NPAD>::WPS)
 k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__restrict__ obs,
       float *__restrict__ reward, uint8_t *__restrict__ done, OT *__restrict__ a_prior)
 {
@@ -300,8 +306,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int k = 0; k < kTopoMax; ++k)
             if (k < P.topo) pj[k] = P.nei[((size_t)e * n_a + i) * P.topo + k];
     }
-    // ---- stage the target cells (ENV: grid_center (2, n_g)) in LDS: (x, y) f64 pairs and an fp32 copy laid out
-    // per pair of cells {xa, xb, ya, yb} for packed arithmetic; pad with a sentinel (fp32: +inf)
+    // ---- generic (non-lattice) mode: stage an fp32 copy of the target cells (ENV: grid_center (2, n_g)) in LDS, laid
+    // out per pair of cells {xa, xb, ya, yb} for packed arithmetic, padded with a sentinel (fp32: +inf).  The lattice
+    // walk needs no cell coordinates except on its rare exact paths, which read the fp64 cells from global memory.
+    const bool use_lat = P.lattice != 0;
+    if (!use_lat)
     for (int rep = 0, reps = REPS(9); rep < reps; ++rep)
     for (int k = 0; k < EPB; ++k) {
         FENCE();
@@ -319,8 +328,18 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
-    const bool use_lat = P.lattice != 0;
+    double warm = 0.0;
     if (use_lat) {
+        // lattice mode gathers the fp64 cells from global memory (nearest-cell merge, reward weights, observation
+        // values): one coalesced pass over this workgroup's cells up front brings them into L2 / L1 and the TLB, so the
+        // later per-lane gathers hit instead of each paying a scattered HBM access.  The values are only summed.
+        for (int k = 0; k < EPB; ++k) {
+            const int ek0 = blockIdx.x * EPB + k;
+            const int ek = ek0 < P.n_env ? ek0 : P.n_env - 1;
+            const int ngk = P.n_g[ek];
+            const double *gx = P.cells + (size_t)ek * 2 * P.ng_max, *gy = gx + P.ng_max;
+            for (int c = tid; c < ngk; c += T) warm += gx[c] + gy[c];
+        }
         for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
         for (int w = sx; w <= W; w += WPE) reinterpret_cast<unsigned *>(smem + P.off_cmask)[w * AG + at] = 0;   // rank-select bits (region unused until then)
         for (int q = tid; q < EPB * (P.ngw + 1); q += T) cov[q] = 0;
@@ -331,6 +350,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         if (sx == 0) sflag[at] = 0;
     }
+    asm volatile("" :: "v"(warm));       // keeps the warming loads alive; they retire here, where the barrier waits anyway
     __syncthreads();
     STAMP(1);
 
@@ -566,7 +586,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const bool wave_exact = (P.force_exact != 0) || (__any(lane_far) != 0);
     float best32 = INFINITY, second32 = INFINITY; int bc = 0;
     const f2v pxx = {pxf, pxf}, pyy = {pyf, pyf};
-    float lat_dlt = 0.0f, lat_l2 = 1.0f;
     if (use_lat) {
         // ---- lattice path.  Row b of the lattice holds the cells of columns rowmask[b]; the columns within
         // lattice distance rho of the agent form an interval.  Columns inside the radius shrunk by the margin lat_m
@@ -592,7 +611,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         auto ffs0 = [](MT v) -> int { return (MB == 32 ? __ffs((unsigned)v) : __ffsll((unsigned long long)v)) - 1; };
         // columns lo..hi inclusive, 0 <= lo, hi <= MB-1; empty when hi < lo
         auto range = [](int lo, int hi) -> MT { return hi >= lo ? (MT)((~(MT)0 >> (MB - 1 - hi)) & (~(MT)0 << lo)) : (MT)0; };
-        auto row_run = [&](int b, float rho, double cut, float cut_lo, float cut_hi, unsigned *dst, bool dst_shared) {
+        auto row_run = [&](int b, float rho, double cut, unsigned *dst, bool dst_shared) {
             // columns of row b within lattice distance rho of (apf, bpf); exact test d2 < cut on the boundary columns
             const bool rowok = act && b >= 0 && b < nrows;
             const float dy = (float)b - bpf;
@@ -616,16 +635,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const int a = ffs0(bnd);
                     bnd &= bnd - 1;
                     const int c = rst + popc(rowm & (MT)(((MT)1 << a) - 1));
-                    // fp32 copy first (LDS); the exact fp64 test (global) only inside the fp32 guard band
-                    const float fx = cq_e[(c >> 1) * 4 + (c & 1)] - pxf, fy = cq_e[(c >> 1) * 4 + 2 + (c & 1)] - pyf;
-                    const float d2f = fmaf(fx, fx, fy * fy);
-                    bool in = d2f < cut_lo;
-                    if (wave_exact || (!in && d2f < cut_hi)) {
-                        const double2 g = cell64(c);
-                        const double ex = g.x - px, ey = g.y - py;
-                        in = ex * ex + ey * ey < cut;
-                    }
-                    if (in) acc |= (MT)1 << a;
+                    const double2 g = cell64(c);                             // the reference's test on the stored cell
+                    const double ex = g.x - px, ey = g.y - py;
+                    if (ex * ex + ey * ey < cut) acc |= (MT)1 << a;
                 }
             }
             const MT sel = rowm & acc;
@@ -655,49 +667,72 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
             FENCE();
             const int b0s = (int)floorf(bpf) - P.lat_rw;
-            for (int t = sx; t < 2 * P.lat_rw + 2; t += WPE) row_run(b0s + t, L.R, P.c_sen, P.csen_lo, P.csen_hi, sbits, false);
+            for (int t = sx; t < 2 * P.lat_rw + 2; t += WPE) row_run(b0s + t, L.R, P.c_sen, sbits, false);
             const int b0c = (int)floorf(bpf) - P.lat_cw;
-            for (int t = sx; t < 2 * P.lat_cw + 2; t += WPE) row_run(b0c + t, L.Rc, P.c_occ, P.cocc_lo, P.cocc_hi, cov + el * (P.ngw + 1), true);
+            for (int t = sx; t < 2 * P.lat_cw + 2; t += WPE) row_run(b0c + t, L.Rc, P.c_occ, cov + el * (P.ngw + 1), true);
             // nearest cell (CPP:858-908) from the lattice too: in row b the nearest cell is the set column closest to
             // the agent's column coordinate, on either side of it -- two candidates per row, rows dealt over the splits.
             // best / runner-up are tracked in lattice units; a runner-up within the model's error of the best sends the
             // lane to the exact scan below (cells further out on the same side of a row are >= 1 step^2 worse than that
             // side's candidate, so they are never a runner-up within tolerance).
             best32 = INFINITY; second32 = INFINITY; bc = 0;
-            {
-                // split the row at the agent's column: `dn` = set columns left of it, `up` = right of it; the nearest
-                // of each side is that side's only possible best or runner-up
-                const int ar0 = (int)floorf(apf) + 1;
-                const int a_r = ar0 < 0 ? 0 : (ar0 > MB - 1 ? MB - 1 : ar0);
-                const MT lowm = (MT)(((MT)1 << a_r) - 1);                    // columns < a_r
-                const int nr_hi = EPB == 1 ? nrows : 64;
-                for (int b = sx; b < nr_hi; b += WPE) {
-                    const MT rowm = (EPB == 1 || b < nrows) ? rowmask(b) : (MT)0;
-                    const int rst = rs[b];
-                    const float dy = (float)b - bpf, dy2 = dy * dy;
-                    const MT up = rowm >> a_r, dn = rowm & lowm;
-                    const int below_cnt = popc(dn);
-                    const int a_up = a_r + ffs0(up);
-                    const int a_dn = MB - 1 - (MB == 32 ? __clz((int)dn) : __clzll((long long)dn));
-                    const float dxu = (float)a_up - apf, dxd = (float)a_dn - apf;
-                    const float d2u = (act && up != 0) ? fmaf(dxu, dxu, dy2) : INFINITY;
-                    const float d2d = (act && dn != 0) ? fmaf(dxd, dxd, dy2) : INFINITY;
-                    // lower cell index first: on an exact tie the strict compare keeps it (and the tie is re-done exactly)
-                    second32 = __builtin_amdgcn_fmed3f(best32, second32, d2d);
-                    bool lt = d2d < best32;
-                    best32 = lt ? d2d : best32; bc = lt ? rst + below_cnt - 1 : bc;
-                    second32 = __builtin_amdgcn_fmed3f(best32, second32, d2u);
-                    lt = d2u < best32;
-                    best32 = lt ? d2u : best32; bc = lt ? rst + below_cnt : bc;
+            // split the row at the agent's column: `dn` = set columns left of it, `up` = right of it; the nearest
+            // of each side is that side's only possible best or runner-up
+            const int ar0 = (int)floorf(apf) + 1;
+            const int a_r = ar0 < 0 ? 0 : (ar0 > MB - 1 ? MB - 1 : ar0);
+            const MT lowm = (MT)(((MT)1 << a_r) - 1);                        // columns < a_r
+            const int nr_hi = EPB == 1 ? nrows : 64;
+            // candidates of row b: model distance^2 (lattice units) and cell index of the nearest set column on each side
+            auto row_cands = [&](int b, float &d2d, float &d2u, int &c_dn) {
+                const MT rowm = (EPB == 1 || b < nrows) ? rowmask(b) : (MT)0;
+                const float dy = (float)b - bpf, dy2 = dy * dy;
+                const MT up = rowm >> a_r, dn = rowm & lowm;
+                const int a_up = a_r + ffs0(up);
+                const int a_dn = MB - 1 - (MB == 32 ? __clz((int)dn) : __clzll((long long)dn));
+                const float dxu = (float)a_up - apf, dxd = (float)a_dn - apf;
+                d2u = (act && up != 0) ? fmaf(dxu, dxu, dy2) : INFINITY;
+                d2d = (act && dn != 0) ? fmaf(dxd, dxd, dy2) : INFINITY;
+                c_dn = rs[b] + popc(dn) - 1;                                 // the `up` candidate is cell c_dn + 1
+            };
+            for (int b = sx; b < nr_hi; b += WPE) {
+                float d2d, d2u; int c_dn;
+                row_cands(b, d2d, d2u, c_dn);
+                // lower cell index first: on an exact tie the strict compare keeps it (and the tie is re-done exactly)
+                second32 = __builtin_amdgcn_fmed3f(best32, second32, d2d);
+                bool lt = d2d < best32;
+                best32 = lt ? d2d : best32; bc = lt ? c_dn : bc;
+                second32 = __builtin_amdgcn_fmed3f(best32, second32, d2u);
+                lt = d2u < best32;
+                best32 = lt ? d2u : best32; bc = lt ? c_dn + 1 : bc;
+            }
+            // runner-up within the model's error of the best (|coordinate error| <= 2^-23 max(|a|, |b|) from the fp32
+            // cast + 1e-6 lattice fit tolerance, in steps): decide among this split's candidates with the reference's
+            // fp64 distances, first minimum in ascending cell order (rows ascending, left candidate before right).
+            const float lat_dlt = 1.2e-7f * fmaxf(fabsf(apf), fabsf(bpf)) + 2e-6f;
+            const float tol = 6.0f * sqrtf(second32) * lat_dlt + 1e-9f;
+            const bool unc_min = act && (wave_exact || (second32 < INFINITY && (second32 - best32) <= tol));
+            if (__any(unc_min)) {
+                if (unc_min) {
+                    const float thr = wave_exact ? INFINITY : best32 + tol;
+                    double bestd = INFINITY; int bcd = bc;
+                    for (int b = sx; b < nr_hi; b += WPE) {
+                        float d2d, d2u; int c_dn;
+                        row_cands(b, d2d, d2u, c_dn);
+                        const bool td = d2d <= thr, tu = d2u <= thr && d2u < INFINITY;
+                        if ((td && d2d < INFINITY) || tu) {
+                            const double2 g0 = cell64((td && d2d < INFINITY) ? c_dn : 0), g1 = cell64(tu ? c_dn + 1 : 0);
+                            const double e0x = g0.x - px, e0y = g0.y - py, e1x = g1.x - px, e1y = g1.y - py;
+                            const double q0 = e0x * e0x + e0y * e0y, q1 = e1x * e1x + e1y * e1y;
+                            if (td && d2d < INFINITY && q0 < bestd) { bestd = q0; bcd = c_dn; }
+                            if (tu && q1 < bestd) { bestd = q1; bcd = c_dn + 1; }
+                        }
+                    }
+                    bc = bcd;
                 }
             }
         }
         };
         if (P.lat_n32) walk(0u); else walk((u64)0);
-        // from lattice units to the fp32-copy units of the exact re-scan below, with the model's error bound:
-        // |coordinate error| <= 2^-23 max(|a|, |b|) (fp32 cast) + 1e-6 (lattice fit tolerance) steps
-        lat_dlt = 1.2e-7f * fmaxf(fabsf(apf), fabsf(bpf)) + 2e-6f;
-        lat_l2 = (float)P.d_sen * __builtin_amdgcn_rcpf(L.R); lat_l2 *= lat_l2;    // (cell size)^2; 1 ulp is inside the 1.0001 factor
     } else
     for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
     FENCE();
@@ -761,22 +796,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         else if (lane < 32) cmask[(size_t)(w * 32 + lane) * NW + aw] = mym;
     }
     }
-    {   // nearest cell of this split: unambiguous in fp32 unless the runner-up is within tolerance
-        float tol, thr_amb;
-        if (use_lat) {      // lattice units; the re-scan threshold converted to real units, widened for the fp32 copy
-            tol = 6.0f * sqrtf(second32) * lat_dlt + 1e-9f;
-            const float t = (best32 + tol) * lat_l2 * 1.0001f;
-            thr_amb = t + P.min_tol_a * sqrtf(t) + P.min_tol_b * t + 1e-9f;
-        } else {
-            tol = P.min_tol_a * sqrtf(second32) + P.min_tol_b * second32 + 1e-9f;
-            thr_amb = best32 + tol;
-        }
+    if (!use_lat) {   // nearest cell of this split: unambiguous in fp32 unless the runner-up is within tolerance
+        const float tol = P.min_tol_a * sqrtf(second32) + P.min_tol_b * second32 + 1e-9f;
         const bool unc_min = act && (wave_exact || (second32 < INFINITY && (second32 - best32) <= tol));
         if (__any(unc_min)) {
-            const float thr = unc_min ? (wave_exact ? INFINITY : thr_amb) : -1.0f;
+            const float thr = unc_min ? (wave_exact ? INFINITY : best32 + tol) : -1.0f;
             double bestd = INFINITY; int bcd = bc;
             for (int w = 0; w < W; ++w) {
-                if (!use_lat && !mine(w)) continue;          // lattice: rows, not words, were dealt out -- scan them all
+                if (!mine(w)) continue;
                 for (int b = 0; b < 32; ++b) {
                     const int cc = w * 32 + b;
                     const float rx = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf, ry = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf;
@@ -998,7 +1025,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int q = sx; q < G; q += WPE) {
             if (q < lim) {
                 const int cc = row[q];
-                const float x = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf, y = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf;
+                float x, y;
+                if (use_lat) { x = (float)gxe[cc] - pxf; y = (float)gye[cc] - pyf; }     // cc < ng: a sensed cell
+                else { x = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf; y = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf; }
                 const float psi = psi_u_f32(fmaf(x, x, y * y) * inv_dsen2);
                 num0 = fmaf(psi, x, num0); num1 = fmaf(psi, y, num1); den += psi;
             }
@@ -1020,12 +1049,13 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const float v0f = n0 / dn, v1f = n1 / dn;
         const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
         uniform = has && vf < 0.05f;
-        const bool unsure = has && (P.force_exact || !(dn > 1e-3f) || !(fabsf(vf - 0.05f) > P.rew_guard));
+        const bool unsure = has && (P.force_exact || !(dn > 1e-6f) || !(fabsf(vf - 0.05f) > P.rew_ga * (float)n_sel / dn + P.rew_gb));
         if (__any(unsure)) {
             if (unsure) {      // exact: fp64, slot order (CPP:529-549)
                 const double inv_dsen = 1.0 / P.d_sen;
                 const short *row = sidx + (size_t)at * P.g_stride;
                 double num0 = 0.0, num1 = 0.0, den = 0.0;
+#pragma unroll 4
                 for (int q = 0; q < n_sel; ++q) {
                     const double2 g = cell64(row[q]);
                     const double x = g.x - px, y = g.y - py;
@@ -1599,7 +1629,6 @@ void layout_t(KP &k)
     k.off_cxy = 0;                             // fp64 cells are no longer staged in LDS
     k.off_sp = take((size_t)4 * AG * 8);
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
-    k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
     k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * 2 * NW * AG * 8));  // sidx | pm
@@ -1611,9 +1640,11 @@ void layout_t(KP &k)
     k.off_sncf = take((size_t)AG * 4);
     k.off_snear = take((size_t)NW * AG * 8);
     k.off_pc = take((size_t)k.ngw * AG);
-    k.smem_bytes = (int)off;
+    k.smem_lat = (int)off;                           // lattice mode, no export
     k.off_obits = take((size_t)k.ngw * AG * 4);      // only launches that export the index scratch use it
-    k.smem_bytes_export = (int)off;
+    k.smem_lat_export = (int)off;
+    k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);   // fp32 cell copy: the generic (non-lattice) scan only
+    k.smem_generic = (int)off;
 }
 
 void layout(KP &k, int npad)
@@ -1633,7 +1664,10 @@ int launch_t(swarm_env *h, const void *action, int act_f64, void *obs, float *re
 {
     constexpr int T = Geo<NPAD>::T, EPB = Geo<NPAD>::EPB;
     auto kern = k_env<NPAD, OT, DO_STEP>;
-    const int smem = h->kp.export_idx ? h->kp.smem_bytes_export : h->kp.smem_bytes;
+    int smem = !h->kp.lattice ? h->kp.smem_generic : (h->kp.export_idx ? h->kp.smem_lat_export : h->kp.smem_lat);
+#ifdef SWARM_EXTRA_SMEM
+    smem += SWARM_EXTRA_SMEM;                            // occupancy experiments only
+#endif
     int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : 0)];   // raise the dynamic-LDS cap once per size
     if (attr < smem) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1764,7 +1798,15 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
         k.cocc_lo = f_below(k.c_occ - band(k.c_occ)); k.cocc_hi = f_above(k.c_occ + band(k.c_occ));
         k.coord_lim = (float)S;
         k.min_tol_a = (float)(2.0 * 3.0 * dr); k.min_tol_b = (float)(2.0 * std::ldexp(1.0, -21));
-        k.rew_guard = 1.0e-4f;          // fp32 |v| error is < 1e-5 for <= 4096 list entries
+        {   // error bound of the fp32 reward sums near the 0.05 threshold, v = |sum psi r| / sum psi over n list entries:
+            // each fp32 component of r is off by dx (two float conversions + the subtraction), u = |r|^2 / d_sen^2 by
+            // du <= 2 sqrt(2) dx / d_sen, psi by |dpsi/du| du + the polynomial's 4e-7 with |dpsi/du| <= pi^2 / 4; hence
+            // |dv| <= n (dpsi d_sen + dx + 0.05 dpsi) / den + (fp32 accumulation, division, sqrt: < 3e-6).  1.3x margin.
+            const double dx = 2.1 * std::ldexp(1.0, -24) * S;
+            const double dpsi = 2.4675 * (2.0 * std::sqrt(2.0) * dx / k.d_sen) + 4e-7;
+            k.rew_ga = (float)(1.3 * (dpsi * k.d_sen + dx + 0.0505 * dpsi));
+            k.rew_gb = 4e-6f;
+        }
         k.force_exact = (cfg->debug_flags & 1) ? 1 : 0;
         {   // unsigned division by D = 2 (G-1) (Granlund-Montgomery round-up method, exact for every 32-bit x)
             const unsigned D = 2u * (unsigned)(k.g_max - 1);
@@ -1785,7 +1827,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     if (!g.ok) { delete h; return fail(nullptr, SWARM_ERR_HIP, "hipSetDevice failed"); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(nullptr, SWARM_ERR_HIP, "hipGetDeviceProperties failed"); }
-    if ((size_t)k.smem_bytes_export > 160 * 1024) {
+    if ((size_t)k.smem_generic > 160 * 1024) {
         delete h;
         return fail(nullptr, SWARM_ERR_INVALID, "configuration needs more LDS per workgroup than the device has (reduce n_cells_max / num_obs_grid_max)");
     }
