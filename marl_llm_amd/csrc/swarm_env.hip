@@ -1050,9 +1050,51 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
         uniform = has && vf < 0.05f;
         const bool unsure = has && (P.force_exact || !(dn > 1e-6f) || !(fabsf(vf - 0.05f) > P.rew_ga * (float)n_sel / dn + P.rew_gb));
-        if (__any(unsure)) {
-            if (unsure) {      // exact: fp64, slot order (CPP:529-549)
-                const double inv_dsen = 1.0 / P.d_sen;
+        u64 um = __ballot(unsure);
+        if (um != 0) {
+            const double inv_dsen = 1.0 / P.d_sen;
+            if constexpr (NW == 1) {
+                // exact (CPP:529-549), wave-cooperative: for each unsure agent (rarely more than one per wave) the 64 lanes
+                // evaluate one list slot each in fp64 -- psi needs a sqrt and a 12-term cosine -- and park the three
+                // products in LDS; the sums then run over them sequentially in slot order, which is the reference's
+                // order of additions.  (A lane looping alone over its list made this workgroup a straggler.)
+                double *scr = reinterpret_cast<double *>(smem + P.off_cmask);       // [3][64]; rsum (read above) is dead
+                while (um != 0) {
+                    const int L = __ffsll((unsigned long long)um) - 1;               // agent thread, wave-uniform
+                    um &= um - 1;
+                    const int nL = __builtin_amdgcn_readlane(n_sel, L);
+                    const int eL = blockIdx.x * EPB + (NPAD < 64 ? L / NPAD : 0);
+                    const double *gxl = P.cells + (size_t)eL * 2 * P.ng_max, *gyl = gxl + P.ng_max;
+                    const double pxl = sp[L], pyl = sp[AG + L];
+                    const short *rowl = sidx + (size_t)L * P.g_stride;
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+                    for (int base = 0; base < nL; base += 64) {
+                        const int q = base + lane;
+                        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+                        if (q < nL) {
+                            const int cc = rowl[q];
+                            const double x = gxl[cc] - pxl, y = gyl[cc] - pyl;
+                            const double z = sqrt(x * x + y * y);
+                            // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
+                            const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
+                            t0 = psi * x; t1 = psi * y; t2 = psi;
+                        }
+                        scr[lane] = t0; scr[64 + lane] = t1; scr[128 + lane] = t2;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const int m = nL - base < 64 ? nL - base : 64;
+#pragma unroll 8
+                        for (int t = 0; t < m; ++t) { a0 += scr[t]; a1 += scr[64 + t]; a2 += scr[128 + t]; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (a2 == 0) a2 = 1E-8;
+                    const double v0 = 1.0 * a0 / a2, v1 = 1.0 * a1 / a2;
+                    const bool res = sqrt(v0 * v0 + v1 * v1) < 0.05;
+                    if (lane == L) uniform = res;
+                }
+            } else if (unsure) {      // exact: fp64, slot order (CPP:529-549)
                 const short *row = sidx + (size_t)at * P.g_stride;
                 double num0 = 0.0, num1 = 0.0, den = 0.0;
 #pragma unroll 4
@@ -1060,7 +1102,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const double2 g = cell64(row[q]);
                     const double x = g.x - px, y = g.y - py;
                     const double z = sqrt(x * x + y * y);
-                    // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
                     const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
                     num0 += psi * x; num1 += psi * y; den += psi;
                 }

@@ -1,4 +1,5 @@
 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-for L in libswarmenv_w5.so libswarmenv.so; do for E in 4096 16384; do
-SWARM_LIB=marl_llm_amd/lib/$L python bench.py --no-cpu-baseline --envs $E --steps 100 2>/dev/null | python tools/_fmt.py $L
-done; done
+for E in 1280 4096 16384; do
+python bench.py --no-cpu-baseline --envs $E --steps 100 2>/dev/null | python tools/_fmt.py main
+done
+python bench.py --no-cpu-baseline --state scatter 2>/dev/null | python tools/_fmt.py scatter
