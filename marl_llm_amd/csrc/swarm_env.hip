@@ -86,7 +86,8 @@ struct KP {
     double bx0, by1, bx2, by3, w_half, h_half;
     double *p, *dp;
     int *nei, *near_cell, *in_flag;
-    const double *cells;
+    const double *cells;       // [E][2][ng_max] (the ABI's layout)
+    const double2 *cells_xy;   // [E][ng_max] (x, y) interleaved copy: one 16-byte gather per cell
     const int *n_g;
     const double *c_in;
     int *exp_sensed, *exp_occ;
@@ -280,8 +281,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     };
     // exact (fp64) cell coordinates are read from global memory where they are needed (prior target, nearest-cell
     // merge, observation values, the rare exact fallbacks); the env's 8.7 KB of cells stay L1/L2 resident.
-    const double *gxe = P.cells + (size_t)es * 2 * P.ng_max, *gye = gxe + P.ng_max;
-    auto cell64 = [&](int c) -> double2 { double2 g; g.x = c < ng ? gxe[c] : kSentinel; g.y = c < ng ? gye[c] : kSentinel; return g; };
+    const double2 *gce = P.cells_xy + (size_t)es * P.ng_max;
+    auto cell64 = [&](int c) -> double2 { double2 g = gce[c < ng ? c : 0]; if (!(c < ng)) { g.x = kSentinel; g.y = kSentinel; } return g; };
     const float *cq_e = cxq + (size_t)el * P.cxq_stride;
 
     // ---- issue every global load of the step up front (their latency overlaps the cell staging)
@@ -337,8 +338,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const int ek0 = blockIdx.x * EPB + k;
             const int ek = ek0 < P.n_env ? ek0 : P.n_env - 1;
             const int ngk = P.n_g[ek];
-            const double *gx = P.cells + (size_t)ek * 2 * P.ng_max, *gy = gx + P.ng_max;
-            for (int c = tid; c < ngk; c += T) warm += gx[c] + gy[c];
+            const double2 *gq = P.cells_xy + (size_t)ek * P.ng_max;
+            for (int c = tid; c < ngk; c += T) { const double2 g = gq[c]; warm += g.x + g.y; }
         }
         for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
         for (int w = sx; w <= W; w += WPE) reinterpret_cast<unsigned *>(smem + P.off_cmask)[w * AG + at] = 0;   // rank-select bits (region unused until then)
@@ -1026,7 +1027,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             if (q < lim) {
                 const int cc = row[q];
                 float x, y;
-                if (use_lat) { x = (float)gxe[cc] - pxf; y = (float)gye[cc] - pyf; }     // cc < ng: a sensed cell
+                if (use_lat) { const double2 g = gce[cc]; x = (float)g.x - pxf; y = (float)g.y - pyf; }     // cc < ng: a sensed cell
                 else { x = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf; y = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf; }
                 const float psi = psi_u_f32(fmaf(x, x, y * y) * inv_dsen2);
                 num0 = fmaf(psi, x, num0); num1 = fmaf(psi, y, num1); den += psi;
@@ -1064,7 +1065,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     um &= um - 1;
                     const int nL = __builtin_amdgcn_readlane(n_sel, L);
                     const int eL = blockIdx.x * EPB + (NPAD < 64 ? L / NPAD : 0);
-                    const double *gxl = P.cells + (size_t)eL * 2 * P.ng_max, *gyl = gxl + P.ng_max;
+                    const double2 *gcl = P.cells_xy + (size_t)eL * P.ng_max;
                     const double pxl = sp[L], pyl = sp[AG + L];
                     const short *rowl = sidx + (size_t)L * P.g_stride;
                     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -1073,7 +1074,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         double t0 = 0.0, t1 = 0.0, t2 = 0.0;
                         if (q < nL) {
                             const int cc = rowl[q];
-                            const double x = gxl[cc] - pxl, y = gyl[cc] - pyl;
+                            const double2 gq = gcl[cc];
+                            const double x = gq.x - pxl, y = gq.y - pyl;
                             const double z = sqrt(x * x + y * y);
                             // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
                             const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
@@ -1178,7 +1180,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const int ncf = sncf[tr];
                     if (half == 0) {                                    // CPP:136
                         if (ncf >> 30) { a = qx - qx; b = qy - qy; }
-                        else { const double *gr = P.cells + (size_t)(blockIdx.x * EPB + elr) * 2 * P.ng_max; const int cc = ncf & 0xFFFF; a = gr[cc] - qx; b = gr[P.ng_max + cc] - qy; }
+                        else { const double2 g = P.cells_xy[(size_t)(blockIdx.x * EPB + elr) * P.ng_max + (ncf & 0xFFFF)]; a = g.x - qx; b = g.y - qy; }
                     } else {                                            // CPP:137
                         if (ncf >> 30) { a = ux - ux; b = uy - uy; }
                         else { a = 0.0 - ux; b = 0.0 - uy; }
@@ -1200,7 +1202,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             for (int r = wv; r < rows; r += nwv) {
                 const int elr = EPB > 1 ? r / n_a : 0;
                 const int tr = elr * NPAD + (r - elr * n_a);
-                const double *gr = P.cells + (size_t)(blockIdx.x * EPB + elr) * 2 * P.ng_max;
+                const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
                 const double qx = sp[tr], qy = sp[AG + tr];
                 const short *srow = sidx + (size_t)tr * P.g_stride;
                 OT2 *orow = out + (size_t)r * PPR + HP;
@@ -1208,7 +1210,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const int q = ch * 64 + lane;
                     const int c = srow[q];
                     double a = 0.0, b = 0.0;
-                    if (c >= 0) { a = gr[c] - qx; b = gr[P.ng_max + c] - qy; }
+                    if (c >= 0) { const double2 g = gr[c]; a = g.x - qx; b = g.y - qy; }
                     OT2 o; o.x = (OT)a; o.y = (OT)b;
                     orow[q] = o;
                 }
@@ -1223,10 +1225,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     if (r < rows && q < Gp) {
                         const int elr = EPB > 1 ? r / n_a : 0;
                         const int tr = elr * NPAD + (r - elr * n_a);
-                        const double *gr = P.cells + (size_t)(blockIdx.x * EPB + elr) * 2 * P.ng_max;
+                        const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
                         const int c = sidx[(size_t)tr * P.g_stride + q];
                         double a = 0.0, b = 0.0;
-                        if (c >= 0) { a = gr[c] - sp[tr]; b = gr[P.ng_max + c] - sp[AG + tr]; }
+                        if (c >= 0) { const double2 g = gr[c]; a = g.x - sp[tr]; b = g.y - sp[AG + tr]; }
                         OT2 o; o.x = (OT)a; o.y = (OT)b;
                         out[(size_t)r * PPR + HP + q] = o;
                     }
@@ -1501,6 +1503,19 @@ k_rule(const KP P, double *__restrict__ out)     // out [E][N][2]
     }
 }
 
+// (x, y)-interleaved copy of the target cells of envs [e0, e0 + count): the step kernel gathers cells per lane, and one
+// 16-byte load per cell costs half the address-unit work of two 8-byte loads from the ABI's [2][ng_max] layout.
+__global__ void __launch_bounds__(256)
+k_interleave(const double *__restrict__ cells, double2 *__restrict__ out, int ng_max, int e0, int count)
+{
+    const size_t n = (size_t)count * ng_max;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = e0 + q / ng_max, c = q % ng_max;
+        double2 g; g.x = cells[e * 2 * ng_max + c]; g.y = cells[e * 2 * ng_max + ng_max + c];
+        out[e * ng_max + c] = g;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
@@ -1542,6 +1557,7 @@ struct swarm_env {
     std::string err;
     // device buffers
     double *d_p, *d_dp, *d_cells, *d_cin;
+    double2 *d_cells_xy;
     LatEnv *d_lat;
     // shape set for the device-side reset
     int n_shapes;
@@ -1795,7 +1811,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->cfg = *cfg; h->device = dev; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
     h->have_cells = h->have_state = h->observed = false;
     for (int &a : h->attr_smem) a = -1;
-    h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr;
+    h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr; h->d_cells_xy = nullptr;
     h->d_lat = nullptr;
     h->n_shapes = 0; h->d_shape_cells = h->d_shape_l = h->d_shape_cin = nullptr; h->d_shape_ng = nullptr; h->d_shape_lat = nullptr;
     h->shapes_lattice = false; h->shapes_rmax = h->shapes_cmax = 0.0f; h->shapes_ncols = 0;
@@ -1877,6 +1893,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     auto alloc = [&](void **p, size_t bytes) { if (a == hipSuccess) a = hipMalloc(p, bytes); };
     alloc((void **)&h->d_p, E * 2 * N * 8); alloc((void **)&h->d_dp, E * 2 * N * 8);
     alloc((void **)&h->d_cells, E * 2 * (size_t)k.ng_max * 8); alloc((void **)&h->d_cin, E * 8);
+    alloc((void **)&h->d_cells_xy, E * (size_t)k.ng_max * 16);
     alloc((void **)&h->d_ng, E * 4);
     alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
@@ -1886,6 +1903,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     if (a == hipSuccess) a = hipMemset(h->d_near, 0, E * N * 4);
     if (a == hipSuccess) a = hipMemset(h->d_inflag, 0, E * N * 4);
     if (a == hipSuccess) a = hipMemset(h->d_cells, 0, E * 2 * (size_t)k.ng_max * 8);
+    if (a == hipSuccess) a = hipMemset(h->d_cells_xy, 0, E * (size_t)k.ng_max * 16);
     if (a == hipSuccess) a = hipEventCreate(&h->ev0);
     if (a == hipSuccess) a = hipEventCreate(&h->ev1);
     if (a != hipSuccess) {
@@ -1894,7 +1912,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
         return fail(nullptr, SWARM_ERR_HIP, m);
     }
     k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag;
-    k.cells = h->d_cells; k.n_g = h->d_ng; k.c_in = h->d_cin;
+    k.cells = h->d_cells; k.cells_xy = h->d_cells_xy; k.n_g = h->d_ng; k.c_in = h->d_cin;
     k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_n32 = 0;
     k.c_near_hi = k.c_near * (1.0 + 1e-9);
     *out = h;
@@ -1907,7 +1925,7 @@ int swarm_destroy(swarm_env_t *h)
     {
         DeviceGuard g(h->device);
         (void)hipStreamSynchronize(h->stream);
-        (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin);
+        (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin); (void)hipFree(h->d_cells_xy);
         (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag);
         (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat);
         (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
@@ -1949,6 +1967,12 @@ int swarm_set_cells(swarm_env_t *h, int env_begin, int count, const double *cell
     DeviceGuard g(h->device);
     const size_t row = (size_t)2 * h->kp.ng_max;
     HIP_TRY(h, hipMemcpyAsync(h->d_cells + (size_t)env_begin * row, cells, (size_t)count * row * 8, hipMemcpyDefault, h->stream));
+    {
+        const size_t n = (size_t)count * h->kp.ng_max;
+        hipLaunchKernelGGL(k_interleave, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           h->d_cells, h->d_cells_xy, h->kp.ng_max, env_begin, count);
+        HIP_TRY(h, hipGetLastError());
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_ng + env_begin, n_g, (size_t)count * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_cin + env_begin, cin.data(), (size_t)count * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));           // cin is a host temporary
@@ -2038,6 +2062,12 @@ int swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_off
     hipLaunchKernelGGL(k_reset, dim3(h->cfg.n_env), dim3(256), 0, h->stream, h->kp, S, (unsigned long long)seed,
                        (unsigned long long)episode, (long long)env_offset, h->d_cells, h->d_ng, h->d_cin, h->d_lat);
     HIP_TRY(h, hipGetLastError());
+    {
+        const size_t n = (size_t)h->cfg.n_env * h->kp.ng_max;
+        hipLaunchKernelGGL(k_interleave, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           h->d_cells, h->d_cells_xy, h->kp.ng_max, 0, h->cfg.n_env);
+        HIP_TRY(h, hipGetLastError());
+    }
     std::fill(h->cells_set.begin(), h->cells_set.end(), 1);
     std::fill(h->lat_ok.begin(), h->lat_ok.end(), h->shapes_lattice ? 1 : 0);
     // per-env bounds for a later partial swarm_set_cells: the shape set's maxima are valid for every env
