@@ -86,6 +86,7 @@ struct KP {
     double bx0, by1, bx2, by3, w_half, h_half;
     double *p, *dp;
     int *nei, *near_cell, *in_flag;
+    unsigned long long *hit;   // [E][N] (N <= 64): agents overlapping agent i in the CURRENT state (contact pairs of the next step)
     const double *cells;       // [E][2][ng_max] (the ABI's layout)
     const double2 *cells_xy;   // [E][ng_max] (x, y) interleaved copy: one 16-byte gather per cell
     const int *n_g;
@@ -144,6 +145,9 @@ __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
 
 #define REPS(k) ((P.dbg_phase == (k)) ? P.dbg_extra + 1 : 1)
 #define FENCE() asm volatile("" ::: "memory")
+// diagnostics only (tools/ablate.py --cumulative): leave the kernel after segment k (debug phase 15, extra = k); outputs
+// are then incomplete, so only timing / counter runs use it
+#define EXIT_AT(k) do { if (P.dbg_phase == 15 && P.dbg_extra == (k)) return; } while (0)
 
 #ifdef SWARM_STAMPS
 #define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); stamp_t[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -228,7 +232,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     unsigned *obits = reinterpret_cast<unsigned *>(smem + P.off_obits);  // [word][AG] (export launches only)
     short *sidx = reinterpret_cast<short *>(smem + P.off_sidx);          // [AG][g_stride]
     int *part_c = reinterpret_cast<int *>(smem + P.off_partc);           // [WPE][AG] per-split nearest-cell candidates
-    u64 *pm = reinterpret_cast<u64 *>(smem + P.off_sidx);                // [WPE][2][AG] partial pair masks (aliases sidx, earlier phase)
+    u64 *pm = reinterpret_cast<u64 *>(smem + P.off_sidx);                // [WPE][2 or 3][NW][AG] partial pair masks (aliases sidx, earlier phase)
     unsigned *owords = reinterpret_cast<unsigned *>(smem + P.off_cmask); // [word][AG] occupied bits (NW == 1; aliases cmask)
     short *snei = reinterpret_cast<short *>(smem + P.off_snei);          // [AG][kTopoMax]
     int *sncf = reinterpret_cast<int *>(smem + P.off_sncf);              // [AG]: nearest cell | in_flag<<30
@@ -292,7 +296,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     int pj[kTopoMax]; int ncell = 0, inf = 0;
 #pragma unroll
     for (int k = 0; k < kTopoMax; ++k) pj[k] = -1;
+    u64 hit0 = 0;
     if (sx == 0 && act) {
+        if (DO_STEP && NW == 1) hit0 = P.hit[(size_t)e * n_a + i];
         px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
         vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
         if (DO_STEP) {
@@ -354,6 +360,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     asm volatile("" :: "v"(warm));       // keeps the warming loads alive; they retire here, where the barrier waits anyway
     __syncthreads();
     STAMP(1);
+    EXIT_AT(0);
 
     if (DO_STEP) {
         if (sx == SB && SB != 0) { px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at]; }
@@ -406,18 +413,24 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 constexpr int KN = NPAD < 64 ? NPAD : 64;
                 const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
                 u64 hit[NW];
+                if constexpr (NW == 1) {
+                    // the previous observation pass evaluated exactly this test on exactly these positions (its
+                    // post-integration state is this step's pre-integration state) and left the mask in HBM
+                    hit[0] = hit0;
+                } else {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    u64 h = 0;
+                    for (int w = 0; w < NW; ++w) {
+                        u64 h = 0;
 #pragma unroll 8
-                    for (int kk = 0; kk < KN; ++kk) {
-                        const double dx = spx[w * 64 + kk] - px, dy = spy[w * 64 + kk] - py;
-                        const double d2 = dx * dx + dy * dy;
-                        if (d2 < P.c_ball) h |= 1ull << kk;
+                        for (int kk = 0; kk < KN; ++kk) {
+                            const double dx = spx[w * 64 + kk] - px, dy = spy[w * 64 + kk] - py;
+                            const double d2 = dx * dx + dy * dy;
+                            if (d2 < P.c_ball) h |= 1ull << kk;
+                        }
+                        hit[w] = h;
                     }
-                    hit[w] = h;
+                    if (i < 64 * NW) hit[i >> 6] &= ~(1ull << (i & 63));       // k != i
                 }
-                if (i < 64 * NW) hit[NPAD <= 64 ? 0 : (i >> 6)] &= ~(1ull << (i & 63));       // k != i
                 // pass B: the colliding pairs in ascending k (the reference's summation order, CPP:799-807)
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
@@ -479,6 +492,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at];
     STAMP(2);
+    EXIT_AT(1);
 
     // ---- pairwise masks + neighbour search, CPP:77-100 + _get_focused CPP:628-698: the topo nearest agents with
     // norm < d_sen (self removed), ascending; and the "nearby" agent mask of the occupied-cell filter
@@ -493,13 +507,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     u64 nearbyN[NW], candN[NW];
     {
         constexpr int JQ = (JN + WPE - 1) / WPE;
-        u64 nb[NW], cd[NW];
+        constexpr int PMK = NW == 1 ? 3 : 2;          // partial masks per split: nearby, candidates, (N <= 64) contacts
+        u64 nb[NW], cd[NW], ht[NW];
         double exc_lo = INFINITY;
         for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
             FENCE();
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                nb[w] = 0; cd[w] = 0;
+                nb[w] = 0; cd[w] = 0; ht[w] = 0;
 #pragma unroll
                 for (int q = 0; q < JQ; ++q) {
                     const int jj = sx * JQ + q;
@@ -507,6 +522,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
                         const double d2u = rx * rx + ry * ry;
                         if (d2u < P.c_near) nb[w] |= 1ull << jj;
+                        if (NW == 1 && d2u < P.c_ball) ht[w] |= 1ull << jj;      // contact pairs of the NEXT step (ENV:442-457)
                         exc_lo = fmin(exc_lo, d2u >= P.c_near ? d2u : INFINITY);   // closest NON-nearby agent (see the occupied-cell filter)
                         double d2 = d2u;
                         if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
@@ -519,18 +535,28 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
-            pm[((sx * 2 + 0) * NW + w) * AG + at] = NPAD < 64 ? (nb[w] << (el * NPAD)) : nb[w];
-            pm[((sx * 2 + 1) * NW + w) * AG + at] = cd[w];
+            pm[((sx * PMK + 0) * NW + w) * AG + at] = NPAD < 64 ? (nb[w] << (el * NPAD)) : nb[w];
+            pm[((sx * PMK + 1) * NW + w) * AG + at] = cd[w];
+            if constexpr (NW == 1) pm[((sx * PMK + 2) * NW + w) * AG + at] = ht[w];
         }
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             nearbyN[w] = 0; candN[w] = 0;
 #pragma unroll
-            for (int q = 0; q < WPE; ++q) { nearbyN[w] |= pm[((q * 2 + 0) * NW + w) * AG + at]; candN[w] |= pm[((q * 2 + 1) * NW + w) * AG + at]; }
+            for (int q = 0; q < WPE; ++q) { nearbyN[w] |= pm[((q * PMK + 0) * NW + w) * AG + at]; candN[w] |= pm[((q * PMK + 1) * NW + w) * AG + at]; }
+        }
+        if constexpr (NW == 1) {
+            if (sx == 0 && act) {
+                u64 hh = 0;
+#pragma unroll
+                for (int q = 0; q < WPE; ++q) hh |= pm[((q * PMK + 2) * NW) * AG + at];
+                P.hit[(size_t)e * n_a + i] = hh & ~(1ull << i);               // k != i
+            }
         }
     }
     const u64 nearby1 = nearbyN[0];
+    EXIT_AT(2);
     if (sx == SB) for (int rep = 0, reps = REPS(10); rep < reps; ++rep) {
         FENCE();
         bool collision = false;
@@ -575,6 +601,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         snei[at * kNeiStride + kTopoMax] = (short)(collision ? 1 : 0);
     }
     STAMP(3);
+    EXIT_AT(3);
 
     // ---- target-cell scan over this split's words, _get_target_grid_state CPP:858-908: first-minimum
     // nearest cell, sensed-cell bits (d < d_sen), and per cell the ballot of agents with d <= r_avoid/2
@@ -602,6 +629,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const float lat_m = fmaxf(1e-4f, 8e-7f * fmaxf(fabsf(apf), fabsf(bpf)));
         const u64 *rm = lrm + el * 64;
         const short *rs = lrs + el * 64;
+        // Rows are dealt over the splits other than B: B runs the ordered neighbour insertion meanwhile (about one
+        // split's share of the walk), so no split is the straggler at the barrier that follows.
+        constexpr int WS = WPE > 1 ? WPE - 1 : 1;
+        const int wr = WPE > 1 ? (sx < SB ? sx : sx - 1) : 0;
         // The walk is instantiated for 32-bit row masks (every env's lattice has <= 32 columns: the reference's shapes
         // do) and for 64-bit ones.
         auto walk = [&](auto tag) {
@@ -668,9 +699,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
             FENCE();
             const int b0s = (int)floorf(bpf) - P.lat_rw;
-            for (int t = sx; t < 2 * P.lat_rw + 2; t += WPE) row_run(b0s + t, L.R, P.c_sen, sbits, false);
+            for (int t = wr; t < 2 * P.lat_rw + 2; t += WS) row_run(b0s + t, L.R, P.c_sen, sbits, false);
             const int b0c = (int)floorf(bpf) - P.lat_cw;
-            for (int t = sx; t < 2 * P.lat_cw + 2; t += WPE) row_run(b0c + t, L.Rc, P.c_occ, cov + el * (P.ngw + 1), true);
+            for (int t = wr; t < 2 * P.lat_cw + 2; t += WS) row_run(b0c + t, L.Rc, P.c_occ, cov + el * (P.ngw + 1), true);
             // nearest cell (CPP:858-908) from the lattice too: in row b the nearest cell is the set column closest to
             // the agent's column coordinate, on either side of it -- two candidates per row, rows dealt over the splits.
             // best / runner-up are tracked in lattice units; a runner-up within the model's error of the best sends the
@@ -695,7 +726,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 d2d = (act && dn != 0) ? fmaf(dxd, dxd, dy2) : INFINITY;
                 c_dn = rs[b] + popc(dn) - 1;                                 // the `up` candidate is cell c_dn + 1
             };
-            for (int b = sx; b < nr_hi; b += WPE) {
+            for (int b = wr; b < nr_hi; b += WS) {
                 float d2d, d2u; int c_dn;
                 row_cands(b, d2d, d2u, c_dn);
                 // lower cell index first: on an exact tie the strict compare keeps it (and the tie is re-done exactly)
@@ -716,7 +747,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 if (unc_min) {
                     const float thr = wave_exact ? INFINITY : best32 + tol;
                     double bestd = INFINITY; int bcd = bc;
-                    for (int b = sx; b < nr_hi; b += WPE) {
+                    for (int b = wr; b < nr_hi; b += WS) {
                         float d2d, d2u; int c_dn;
                         row_cands(b, d2d, d2u, c_dn);
                         const bool td = d2d <= thr, tu = d2u <= thr && d2u < INFINITY;
@@ -733,7 +764,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         }
         };
-        if (P.lat_n32) walk(0u); else walk((u64)0);
+        if (sx != SB || WPE == 1) { if (P.lat_n32) walk(0u); else walk((u64)0); }
     } else
     for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
     FENCE();
@@ -820,6 +851,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     part_c[sx * AG + at] = bc;
+    EXIT_AT(4);
     __syncthreads();
     // merge the splits' candidates exactly: (d2 in fp64, cell index) lexicographic minimum = first minimum
     double best = INFINITY; bc = 0;
@@ -844,6 +876,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     STAMP(4);
+    EXIT_AT(5);
 
     // ---- occupied-cell filter, CPP:144-216: a sensed cell is occupied iff some nearby agent is within
     // r_avoid/2 of it; only agents inside the shape filter (CPP:150).
@@ -912,6 +945,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     __syncthreads();
     STAMP(5);
+    EXIT_AT(6);
 
     // ---- capped sensed list (CPP:236-271) into LDS, and the exploration reward's sums over it (CPP:494-551).
     // Each split emits the slots of its own words (rank = prefix of the kept-bit counts) and accumulates
@@ -954,6 +988,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     __syncthreads();
+    EXIT_AT(7);
     // (2) emit: every split walks the words in order to carry the running rank / slot counters; it writes the
     // slots of its own words.
     {
@@ -1011,6 +1046,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
     }
     __syncthreads();
+    EXIT_AT(8);
     // exploration-reward sums over the capped list (CPP:494-551), fp32 fast path: split sx takes slots
     // sx, sx+WPE, ...; independent iterations (unrolled).  The fp32 result only DECIDES when |v| is outside a
     // guard band around the 0.05 threshold; inside it the sums are redone in fp64 below.
@@ -1038,6 +1074,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     __syncthreads();
     STAMP(6);
+    EXIT_AT(9);
 
     if (sx == 0) {
         float n0 = 0.0f, n1 = 0.0f, dn = 0.0f;
@@ -1141,6 +1178,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             for (; os < O; ++os) eo[os] = -1;
         }
     }
+    EXIT_AT(10);
 
     // ---- observation rows, CPP:102-137,274-306, streamed out as (value, value) pairs with consecutive lanes
     // on consecutive addresses (the rows of this workgroup's environments are contiguous in HBM).  Two passes with
@@ -1192,6 +1230,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 if (q >= HP) { q -= HP; ++r; }
             }
         }
+        EXIT_AT(11);
         for (int rep = 0, reps = REPS(8); rep < reps; ++rep) {
             FENCE();
             // wave per row: lane = slot, so the row's agent position, cell base and output base are wave-uniform
@@ -1570,6 +1609,7 @@ struct swarm_env {
     std::vector<int> lat_ncols;
     bool lattice_disabled;
     int *d_nei, *d_near, *d_inflag, *d_ng, *d_exp_sensed, *d_exp_occ;
+    unsigned long long *d_hit;
 };
 
 namespace {
@@ -1688,7 +1728,7 @@ void layout_t(KP &k)
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * 2 * NW * AG * 8));  // sidx | pm
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * (NW == 1 ? 3 : 2) * NW * AG * 8));  // sidx | pm
     k.off_partc = take((size_t)WPE * AG * 4);
     k.off_lat = take((size_t)EPB * 64 * (8 + 2));
     k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
@@ -1819,7 +1859,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->lat_R.assign((size_t)cfg->n_env, 0.0f); h->lat_Rc.assign((size_t)cfg->n_env, 0.0f);
     h->lat_ncols.assign((size_t)cfg->n_env, 0);
     h->lattice_disabled = (cfg->debug_flags & 2) != 0;
-    h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr;
+    h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr; h->d_hit = nullptr;
     h->cells_set.assign((size_t)cfg->n_env, 0);
     h->npad = npad_for(cfg->n_agents);
 
@@ -1897,11 +1937,12 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     alloc((void **)&h->d_ng, E * 4);
     alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
-    alloc((void **)&h->d_inflag, E * N * 4);
+    alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_hit, E * N * 8);
     if (a == hipSuccess) a = hipMemset(h->d_ng, 0, E * 4);
     if (a == hipSuccess) a = hipMemset(h->d_nei, 0xFF, E * N * (size_t)k.topo * 4);
     if (a == hipSuccess) a = hipMemset(h->d_near, 0, E * N * 4);
     if (a == hipSuccess) a = hipMemset(h->d_inflag, 0, E * N * 4);
+    if (a == hipSuccess) a = hipMemset(h->d_hit, 0, E * N * 8);
     if (a == hipSuccess) a = hipMemset(h->d_cells, 0, E * 2 * (size_t)k.ng_max * 8);
     if (a == hipSuccess) a = hipMemset(h->d_cells_xy, 0, E * (size_t)k.ng_max * 16);
     if (a == hipSuccess) a = hipEventCreate(&h->ev0);
@@ -1911,7 +1952,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
         swarm_destroy(h);
         return fail(nullptr, SWARM_ERR_HIP, m);
     }
-    k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag;
+    k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag; k.hit = h->d_hit;
     k.cells = h->d_cells; k.cells_xy = h->d_cells_xy; k.n_g = h->d_ng; k.c_in = h->d_cin;
     k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_n32 = 0;
     k.c_near_hi = k.c_near * (1.0 + 1e-9);
@@ -1926,7 +1967,7 @@ int swarm_destroy(swarm_env_t *h)
         DeviceGuard g(h->device);
         (void)hipStreamSynchronize(h->stream);
         (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin); (void)hipFree(h->d_cells_xy);
-        (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag);
+        (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag); (void)hipFree(h->d_hit);
         (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat);
         (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
         if (h->ev0) (void)hipEventDestroy(h->ev0);

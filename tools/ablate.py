@@ -34,8 +34,9 @@ def run(skip, n_a, E, sy, ra, state, steps=int(os.environ.get('ABLATE_STEPS', '6
 
 
 def main():
-    n_a = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    E = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+    n_a = int(pos[0]) if len(pos) > 0 else 64
+    E = int(pos[1]) if len(pos) > 1 else 4096
     shapes = synthetic_shape_set()
     ra = r_avoid_for(n_a, shapes)
     sy = synthetic_batch(E, n_a, shapes, seed=226)
@@ -46,6 +47,17 @@ def main():
         act = sb.step(act)[3]
     state = [x.cpu().numpy() for x in sb.get_state()]
     sb.close()
+    if "--cumulative" in sys.argv:
+        # leave the kernel after segment k (debug phase 15): cumulative time / counters up to each point
+        segs = ["loads+first barrier", "forces+prior+integrate", "pair masks", "ordered insertion", "cell walk",
+                "nearest merge", "occupied filter", "rank-select", "emit", "reward sums", "reward combine",
+                "obs head pairs", "obs sensed pairs (full kernel)"]
+        prev = 0.0
+        for k, nm in enumerate(segs):
+            ms = run((15 << 8) | (k << 12), n_a, E, sy, ra, state) if k < 12 else run(0, n_a, E, sy, ra, state)
+            print(f"  exit after {nm:32s} {ms * 1e3:8.1f} us   (+{(ms - prev) * 1e3:6.1f})")
+            prev = ms
+        return
     extra = 2
     base = run(0, n_a, E, sy, ra, state)
     print(f"{n_a} agents x {E} envs, assembled, zero action: full kernel {base * 1e3:.1f} us")

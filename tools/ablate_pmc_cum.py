@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Parse a rocprofv3 --pmc CSV of `ABLATE_STEPS=k python tools/ablate.py --cumulative`: counters up to each exit point."""
+import collections, csv, sys
+path, k = sys.argv[1], int(sys.argv[2])
+segs = ["loads+first barrier", "forces+prior+integrate", "pair masks", "ordered insertion", "cell walk", "nearest merge",
+        "occupied filter", "rank-select", "emit", "reward sums", "reward combine", "obs head pairs", "obs sensed pairs (full)"]
+rows = collections.defaultdict(list)
+for r in csv.DictReader(open(path)):
+    if "k_env<" in r["Kernel_Name"] and "true>" in r["Kernel_Name"]:
+        rows[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+for cname, v in rows.items():
+    v.sort()
+    vals = [x[1] for x in v][100:]
+    per = 5 + k
+    print(cname)
+    prev = 0.0
+    for i, nm in enumerate(segs):
+        chunk = vals[i * per + 5:(i + 1) * per]
+        if not chunk:
+            break
+        m = sum(chunk) / len(chunk) / 4096
+        print(f"  up to {nm:32s} {m:9.1f} per env   (+{m - prev:8.1f})")
+        prev = m
