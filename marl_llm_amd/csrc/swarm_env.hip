@@ -66,6 +66,7 @@ struct KP {
     int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear, off_pc;
     int smem_lat, smem_lat_export, smem_generic;   // dynamic LDS bytes by launch kind
     double c_sen, c_near, c_occ, c_avoid, c_ball;     // squared-distance cut-offs
+    double c_close;            // (2.2 r_avoid)^2 capped at c_sen: pre-selection radius of the neighbour insertion (any value is exact)
     // fp32 pre-filter bands: d2_32 < *_lo  =>  exact test true;  d2_32 >= *_hi  =>  exact test false
     float csen_lo, csen_hi, cocc_lo, cocc_hi;
     float coord_lim;           // |coordinate| bound the bands were derived for
@@ -504,53 +505,66 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // every split evaluates 1/WPE of the agents j of each 64-agent group (branch-free, unrolled); the partial masks
     // are OR-combined through LDS so that every lane ends up with its complete "nearby" masks (split B also with the
     // candidate masks)
-    u64 nearbyN[NW], candN[NW];
+    u64 nearbyN[NW], candN[NW], cand1N[NW];
     {
-        constexpr int JQ = (JN + WPE - 1) / WPE;
-        constexpr int PMK = NW == 1 ? 3 : 2;          // partial masks per split: nearby, candidates, (N <= 64) contacts
-        u64 nb[NW], cd[NW], ht[NW];
-        double exc_lo = INFINITY;
+        constexpr int JQ = JN / WPE;                  // agents j per split and 64-agent group
+        static_assert(JQ * WPE == JN && JQ <= 32, "pair pass: JN must split evenly into <= 32 agents per split");
+        constexpr int PMK = NW == 1 ? 4 : 3;          // partial masks per split: nearby, candidates, close candidates, (N <= 64) contacts
+        // One compare + one add-with-carry per test: the compare's lane mask is the carry-in of acc = 2 acc + carry, so
+        // after the JQ agents of this split bit (JQ-1-q) of acc is the answer for agent q; reversed and shifted into
+        // place (agent j = sx*JQ + q) at the end.
+        unsigned a_nb[NW], a_cd[NW], a_c1[NW], a_ht[NW];
+        bool exc = false;
         for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
             FENCE();
+            exc = false;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                nb[w] = 0; cd[w] = 0; ht[w] = 0;
+                a_nb[w] = 0; a_cd[w] = 0; a_c1[w] = 0; a_ht[w] = 0;
+                unsigned a_hi = 0;
 #pragma unroll
                 for (int q = 0; q < JQ; ++q) {
                     const int jj = sx * JQ + q;
-                    if (jj < JN) {
-                        double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
-                        const double d2u = rx * rx + ry * ry;
-                        if (d2u < P.c_near) nb[w] |= 1ull << jj;
-                        if (NW == 1 && d2u < P.c_ball) ht[w] |= 1ull << jj;      // contact pairs of the NEXT step (ENV:442-457)
-                        exc_lo = fmin(exc_lo, d2u >= P.c_near ? d2u : INFINITY);   // closest NON-nearby agent (see the occupied-cell filter)
-                        double d2 = d2u;
-                        if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                        if (d2 < P.c_sen) cd[w] |= 1ull << jj;
-                    }
+                    double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                    const double d2u = rx * rx + ry * ry;
+                    a_nb[w] = shl1_or_mask(a_nb[w], __ballot(d2u < P.c_near));
+                    a_hi = shl1_or_mask(a_hi, __ballot(d2u < P.c_near_hi));
+                    if constexpr (NW == 1) a_ht[w] = shl1_or_mask(a_ht[w], __ballot(d2u < P.c_ball));   // contact pairs of the NEXT step (ENV:442-457)
+                    double d2 = d2u;
+                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
+                    a_cd[w] = shl1_or_mask(a_cd[w], __ballot(d2 < P.c_sen));
+                    a_c1[w] = shl1_or_mask(a_c1[w], __ballot(d2 < P.c_close));
                 }
+                exc = exc || (a_hi != a_nb[w]);        // some agent is not "nearby" by a hair (see the occupied-cell filter)
             }
         }
-        if (use_lat && exc_lo < P.c_near_hi) atomicOr(&sflag[at], 1);     // not "nearby" by a hair: resolve exactly
+        if (use_lat && exc) atomicOr(&sflag[at], 1);   // resolve the occupied-cell filter of this agent exactly
+        auto place = [&](unsigned acc) -> u64 { return (u64)(__brev(acc) >> (32 - JQ)) << (sx * JQ); };
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
-            pm[((sx * PMK + 0) * NW + w) * AG + at] = NPAD < 64 ? (nb[w] << (el * NPAD)) : nb[w];
-            pm[((sx * PMK + 1) * NW + w) * AG + at] = cd[w];
-            if constexpr (NW == 1) pm[((sx * PMK + 2) * NW + w) * AG + at] = ht[w];
+            const u64 nbm = place(a_nb[w]);
+            pm[((sx * PMK + 0) * NW + w) * AG + at] = NPAD < 64 ? (nbm << (el * NPAD)) : nbm;
+            pm[((sx * PMK + 1) * NW + w) * AG + at] = place(a_cd[w]);
+            pm[((sx * PMK + 2) * NW + w) * AG + at] = place(a_c1[w]);
+            if constexpr (NW == 1) pm[((sx * PMK + 3) * NW + w) * AG + at] = place(a_ht[w]);
         }
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            nearbyN[w] = 0; candN[w] = 0;
+            nearbyN[w] = 0; candN[w] = 0; cand1N[w] = 0;
 #pragma unroll
-            for (int q = 0; q < WPE; ++q) { nearbyN[w] |= pm[((q * PMK + 0) * NW + w) * AG + at]; candN[w] |= pm[((q * PMK + 1) * NW + w) * AG + at]; }
+            for (int q = 0; q < WPE; ++q) nearbyN[w] |= pm[((q * PMK + 0) * NW + w) * AG + at];
+            if (sx == SB) {
+#pragma unroll
+                for (int q = 0; q < WPE; ++q) { candN[w] |= pm[((q * PMK + 1) * NW + w) * AG + at]; cand1N[w] |= pm[((q * PMK + 2) * NW + w) * AG + at]; }
+            }
         }
         if constexpr (NW == 1) {
             if (sx == 0 && act) {
                 u64 hh = 0;
 #pragma unroll
-                for (int q = 0; q < WPE; ++q) hh |= pm[((q * PMK + 2) * NW) * AG + at];
+                for (int q = 0; q < WPE; ++q) hh |= pm[((q * PMK + 3) * NW) * AG + at];
                 P.hit[(size_t)e * n_a + i] = hh & ~(1ull << i);               // k != i
             }
         }
@@ -564,9 +578,20 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 #pragma unroll
         for (int k = 0; k < kTopoMax; ++k) { nd[k] = INFINITY; nj[k] = -1; }
         u64 nearby[NW], cand[NW];
+        {
+            // candidates = agents within d_sen, self removed (CPP:672-676).  When at least `topo` of them are within
+            // the smaller radius sqrt(c_close), the topo nearest all come from those (every other one is strictly
+            // farther): insert only them -- same list, far fewer loop trips.
+            u64 c1[NW]; int n1 = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { nearby[w] = nearbyN[w]; cand[w] = candN[w]; }
-        if (i < 64 * NW) cand[NPAD <= 64 ? 0 : (i >> 6)] &= ~(1ull << (i & 63));             // remove self (CPP:672-676)
+            for (int w = 0; w < NW; ++w) { nearby[w] = nearbyN[w]; cand[w] = candN[w]; c1[w] = cand1N[w]; }
+            if (i < 64 * NW) { const u64 self = ~(1ull << (i & 63)); cand[NPAD <= 64 ? 0 : (i >> 6)] &= self; c1[NPAD <= 64 ? 0 : (i >> 6)] &= self; }
+#pragma unroll
+            for (int w = 0; w < NW; ++w) n1 += __popcll(c1[w]);
+            const bool few = n1 >= P.topo;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cand[w] = few ? c1[w] : cand[w];
+        }
         // pass B: ordered insertion of the candidates, ascending j => ties keep the lower index first
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -1238,6 +1263,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const int Gp = P.g_max;
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
             const int nfull = Gp >> 6, tail = Gp & 63;
+#ifdef EXP_UNROLL
+#pragma unroll EXP_UNROLL
+#endif
             for (int r = wv; r < rows; r += nwv) {
                 const int elr = EPB > 1 ? r / n_a : 0;
                 const int tr = elr * NPAD + (r - elr * n_a);
@@ -1728,7 +1756,7 @@ void layout_t(KP &k)
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * (NW == 1 ? 3 : 2) * NW * AG * 8));  // sidx | pm
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * (NW == 1 ? 4 : 3) * NW * AG * 8));  // sidx | pm
     k.off_partc = take((size_t)WPE * AG * 4);
     k.off_lat = take((size_t)EPB * 64 * (8 + 2));
     k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
@@ -1881,6 +1909,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     k.c_occ = cut_le(k.r_avoid / 2.0);                    // !(norm > r_avoid/2)       CPP:185
     k.c_avoid = cut_lt(k.r_avoid);                        // r_avoid > norm            CPP:482
     k.c_ball = cut_lt(k.size2);                           // d_center - sizes < 0      ENV:450-451
+    k.c_close = std::fmin(k.c_sen, (2.2 * k.r_avoid) * (2.2 * k.r_avoid));
     {   // fp32 pre-filter bands.  With |coordinates| <= S, a float-converted coordinate is off by <= 2^-24 S and
         // their float difference by another 2^-24 S at most: dr = 4 * 2^-24 * S bounds each component of the fp32
         // relative position (1.33x margin).  Then |d2_32 - d2_64| <= 2 sqrt(2) |r| dr + O(2^-23 d2) <= 3 sqrt(d2) dr + 2^-21 d2.
