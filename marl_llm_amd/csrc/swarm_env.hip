@@ -108,12 +108,18 @@ __device__ __forceinline__ void wrap_rel(double &x, double &y, double wh, double
     if (y < -hh) y += 2 * hh; else if (y > hh) y -= 2 * hh;
 }
 
+// gfx950 hazard: a VALU instruction that reads an SGPR (lane mask / scalar source) written by a VALU instruction -- the
+// v_cmp that produced the mask -- needs two wait states in between.  The compiler's hazard recogniser inserts them for its
+// own instructions but cannot see inside inline asm, so both helpers below carry their own `s_nop 1` (it stalls only this
+// wave for two cycles; other waves issue meanwhile).  Without it the asm reads a stale mask whenever the scheduler happens
+// to place it right behind the compare.
+
 // old[LANE] = value (wave-uniform value, compile-time lane): one v_writelane_b32 (the lane select must be an
 // inline constant: a second SGPR operand would violate the constant-bus limit).
 template <int LANE>
 __device__ __forceinline__ int writelane_c(int value, int old)
 {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
     return old;
 }
 
@@ -122,7 +128,7 @@ __device__ __forceinline__ int writelane_c(int value, int old)
 __device__ __forceinline__ unsigned shl1_or_mask(unsigned acc, unsigned long long mask)
 {
     unsigned long long carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(mask));
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(mask));
     return acc;
 }
 
