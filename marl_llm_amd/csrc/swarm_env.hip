@@ -1002,11 +1002,25 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
         FENCE();
         const bool sub = n_kept > G;
-        const unsigned nm1 = (unsigned)(n_kept - 1);
-        const double step = sub ? (double)(n_kept - 1) / (G - 1) : 0.0;
-        for (int q = sx; q < n_sel; q += WPE) {
-            unsigned r = (unsigned)q;
-            if (sub) {
+        // lanes under the cap: rank = slot, i.e. bits [0, n_kept) -- whole words, dealt over the splits
+        if (!sub)
+            for (int w = sx; w * 32 < G; w += WPE) {
+                const int left = n_kept - w * 32;
+                if (left > 0) rsel[w * AG + at] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
+            }
+        // capped lanes (rare, usually one or two per wave): wave-cooperative, lane = slot -- G/64 passes per capped agent
+        // instead of every lane looping over its G slots; the capped agents are dealt over the splits
+        u64 sm = __ballot(sub);
+        int k = 0;
+        while (sm != 0) {
+            const int L = __ffsll((unsigned long long)sm) - 1;
+            sm &= sm - 1;
+            if ((k++ % WPE) != sx) continue;
+            const unsigned nm1 = (unsigned)(__builtin_amdgcn_readlane(n_kept, L) - 1);
+            const double step = (double)nm1 / (G - 1);
+            unsigned *rl = rsel + (at & ~63) + L;                                  // agent thread of lane L in this wave
+            for (int q = lane; q < G; q += 64) {
+                unsigned r;
                 if (P.cap_int) {
                     const unsigned x = 2u * (unsigned)q * nm1 + (unsigned)(G - 1);
                     const unsigned hq = __umulhi(x, P.cap_magic);
@@ -1014,8 +1028,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 } else {
                     r = (unsigned)(int)round(q * step);
                 }
+                atomicOr(&rl[(r >> 5) * AG], 1u << (r & 31));
             }
-            atomicOr(&rsel[(r >> 5) * AG + at], 1u << (r & 31));
         }
     }
     __syncthreads();
