@@ -1102,18 +1102,32 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int lim = in_shape ? n_sel : 0;
         for (int rep = 0, reps = REPS(6); rep < reps; ++rep) {
         FENCE();
-        num0 = 0.0f; num1 = 0.0f; den = 0.0f;
-#pragma unroll 4
-        for (int q = sx; q < G; q += WPE) {
-            if (q < lim) {
-                const int cc = row[q];
-                float x, y;
-                if (use_lat) { const double2 g = gce[cc]; x = (float)g.x - pxf; y = (float)g.y - pyf; }     // cc < ng: a sensed cell
-                else { x = cq_e[(cc >> 1) * 4 + (cc & 1)] - pxf; y = cq_e[(cc >> 1) * 4 + 2 + (cc & 1)] - pyf; }
-                const float psi = psi_u_f32(fmaf(x, x, y * y) * inv_dsen2);
-                num0 = fmaf(psi, x, num0); num1 = fmaf(psi, y, num1); den += psi;
+        // two slots per iteration in packed fp32 (v_pk_*_f32): slots q and q + WPE
+        f2v n0v = {0.0f, 0.0f}, n1v = {0.0f, 0.0f}, dnv = {0.0f, 0.0f};
+        const f2v pxx2 = {pxf, pxf}, pyy2 = {pyf, pyf}, inv2 = {inv_dsen2, inv_dsen2};
+#pragma unroll 2
+        for (int q = sx; q < G; q += 2 * WPE) {
+            const bool va = q < lim, vb = q + WPE < lim;
+            const int ca = va ? row[q] : 0, cb = vb ? row[q + WPE] : 0;       // cell 0 stands in for an empty slot (weight zeroed)
+            f2v gx, gy;
+            if (use_lat) { const double2 ga = gce[ca], gb = gce[cb]; gx = f2v{(float)ga.x, (float)gb.x}; gy = f2v{(float)ga.y, (float)gb.y}; }
+            else {
+                gx = f2v{cq_e[(ca >> 1) * 4 + (ca & 1)], cq_e[(cb >> 1) * 4 + (cb & 1)]};
+                gy = f2v{cq_e[(ca >> 1) * 4 + 2 + (ca & 1)], cq_e[(cb >> 1) * 4 + 2 + (cb & 1)]};
             }
+            const f2v x = gx - pxx2, y = gy - pyy2;
+            const f2v u = __builtin_elementwise_fma(x, x, y * y) * inv2;
+            f2v c = {7.969553699e-04f, 7.969553699e-04f};                      // psi_u_f32, both slots at once
+            c = __builtin_elementwise_fma(c, u, f2v{-1.267949212e-02f, -1.267949212e-02f});
+            c = __builtin_elementwise_fma(c, u, f2v{1.175149009e-01f, 1.175149009e-01f});
+            c = __builtin_elementwise_fma(c, u, f2v{-6.675792336e-01f, -6.675792336e-01f});
+            c = __builtin_elementwise_fma(c, u, f2v{2.029347420e+00f, 2.029347420e+00f});
+            c = __builtin_elementwise_fma(c, u, f2v{-2.467400551e+00f, -2.467400551e+00f});
+            c = __builtin_elementwise_fma(c, u, f2v{1.0f, 1.0f});
+            const f2v psi = {va ? c.x : 0.0f, vb ? c.y : 0.0f};
+            n0v = __builtin_elementwise_fma(psi, x, n0v); n1v = __builtin_elementwise_fma(psi, y, n1v); dnv = dnv + psi;
         }
+        num0 = n0v.x + n0v.y; num1 = n1v.x + n1v.y; den = dnv.x + dnv.y;
         }
         rsum[(sx * 3 + 0) * AG + at] = num0; rsum[(sx * 3 + 1) * AG + at] = num1; rsum[(sx * 3 + 2) * AG + at] = den;
     }
@@ -1242,33 +1256,32 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             for (int L = tid; L < total; L += T) {
                 const int elr = EPB > 1 ? r / n_a : 0;
                 const int tr = elr * NPAD + (r - elr * n_a);
-                const double qx = sp[tr], qy = sp[AG + tr], ux = sp[2 * AG + tr], uy = sp[3 * AG + tr];
+                // every pair is (minuend - subtrahend) of the same kind of quantity: half 0 = positions, half 1 =
+                // velocities (the sp array is [px | py | vx | vy], so `half` selects the array pair).  Self block: own
+                // value - 0; neighbour k: neighbour's value - own (zero pair without a neighbour, CPP:79-81); target
+                // block: in shape (own - own), else (cell - own) for the position and (0 - own) for the velocity (CPP:136-137).
                 const int blk = q >> 1, half = q & 1;
-                double a = 0.0, b = 0.0;
-                if (q < HP - 2) {
-                    if (P.with_self && blk == 0) {                      // CPP:103-113
-                        a = half ? ux : qx; b = half ? uy : qy;
-                    } else {
-                        const int j = snei[tr * kNeiStride + (blk - P.with_self)];
-                        if (j >= 0) {
-                            const int tj = elr * NPAD + j;
-                            if (half) { a = sp[2 * AG + tj] - ux; b = sp[3 * AG + tj] - uy; }     // CPP:80-81
-                            else {
-                                a = sp[tj] - qx; b = sp[AG + tj] - qy;                           // CPP:79
-                                if (P.periodic) wrap_rel(a, b, P.w_half, P.h_half);
-                            }
-                        }
-                    }
-                } else {
+                const double *sa = sp + half * 2 * AG;
+                const double own_a = sa[tr], own_b = sa[AG + tr];
+                double ma = own_a, mb = own_b, sa_ = 0.0, sb_ = 0.0;            // self block
+                const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
+                if (is_nei) {
+                    const int j = snei[tr * kNeiStride + (blk - P.with_self)];
+                    const int tj = elr * NPAD + (j < 0 ? 0 : j);
+                    const double na = sa[tj], nb_ = sa[AG + tj];
+                    ma = j >= 0 ? na : 0.0; mb = j >= 0 ? nb_ : 0.0;
+                    sa_ = j >= 0 ? own_a : 0.0; sb_ = j >= 0 ? own_b : 0.0;
+                }
+                if (is_tgt) {
                     const int ncf = sncf[tr];
-                    if (half == 0) {                                    // CPP:136
-                        if (ncf >> 30) { a = qx - qx; b = qy - qy; }
-                        else { const double2 g = P.cells_xy[(size_t)(blockIdx.x * EPB + elr) * P.ng_max + (ncf & 0xFFFF)]; a = g.x - qx; b = g.y - qy; }
-                    } else {                                            // CPP:137
-                        if (ncf >> 30) { a = ux - ux; b = uy - uy; }
-                        else { a = 0.0 - ux; b = 0.0 - uy; }
+                    sa_ = own_a; sb_ = own_b;
+                    if (!(ncf >> 30)) {
+                        ma = 0.0; mb = 0.0;
+                        if (half == 0) { const double2 g = P.cells_xy[(size_t)(blockIdx.x * EPB + elr) * P.ng_max + (ncf & 0xFFFF)]; ma = g.x; mb = g.y; }
                     }
                 }
+                double a = ma - sa_, b = mb - sb_;
+                if (P.periodic && is_nei && half == 0) wrap_rel(a, b, P.w_half, P.h_half);      // CPP:79 relative position, wrapped
                 OT2 o; o.x = (OT)a; o.y = (OT)b;
                 out[(size_t)r * PPR + q] = o;
                 q += dq; r += dr;
