@@ -9,7 +9,8 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRCS = [os.path.join(PKG, "csrc", "swarm_env.hip"), os.path.join(PKG, "csrc", "legacy_shim.hip")]
+SRCS = [os.path.join(PKG, "csrc", "swarm_env.hip"), os.path.join(PKG, "csrc", "legacy_shim.hip"),
+        os.path.join(PKG, "csrc", "policy_mlp.hip")]
 INC = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libswarmenv.so")
@@ -25,7 +26,7 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(LIB):
         return True
-    newest = max([os.path.getmtime(s) for s in SRCS] + [os.path.getmtime(os.path.join(INC, "swarm_env.h"))])
+    newest = max([os.path.getmtime(s) for s in SRCS] + [os.path.getmtime(os.path.join(INC, h)) for h in ("swarm_env.h", "swarm_policy.h")])
     return os.path.getmtime(LIB) < newest
 
 

@@ -5,7 +5,8 @@ ring buffer (train_assembly.py:91-111, maddpg.py:72-87, agents.py:69-96, buffer_
 `[E, N, D]` device tensors that round trip is the bottleneck, so this module keeps the whole transition on the GPU:
 
 * `PolicyMLP`     -- the reference's actor shape (networks.py:6-44: 4 x Linear, leaky-ReLU, tanh out) as a plain torch
-                     module (hipBLASLt GEMMs; nothing to hand-write: agents are batch rows).
+                     module (the learner trains this one).
+* `FusedPolicy`   -- the same forward as one hand-written bf16-MFMA kernel (csrc/policy_mlp.hip) for the rollout.
 * `DeviceReplay`  -- the ring buffer of buffer_agent.py:13-128 with one row per (env, agent) transition, as device tensors.
 * `rollout`       -- obs -> policy -> exploration noise (agents.py:82-96 continuous branch) -> env.step_tensor -> push.
 
@@ -29,6 +30,60 @@ class PolicyMLP(nn.Module):
         h = F.leaky_relu(self.fc2(h))
         h = F.leaky_relu(self.fc3(h))
         return torch.tanh(self.fc4(h))
+
+
+class FusedPolicy:
+    """The same actor evaluated by ONE hand-written HIP kernel (csrc/policy_mlp.hip: bf16 MFMA, fp32 accumulate, the four
+    layers chained through the accumulator registers) instead of four hipBLASLt GEMMs + elementwise kernels.  Inference
+    only (rollouts); numerics = torch.autocast(bfloat16) on the module.  Built from a PolicyMLP (or any module with
+    fc1..fc4); call `refresh()` after the learner updated the weights.  No CPU path."""
+
+    def __init__(self, module, device="cuda:0"):
+        import ctypes
+        from . import _lib
+        self._ctypes = ctypes
+        self.lib = _lib.load()
+        self.module = module
+        self.device = torch.device(device)
+        self.handle = None
+        self.refresh()
+
+    def refresh(self):
+        ct = self._ctypes
+        m = self.module
+        ws = [t.detach().to("cpu", torch.float32).contiguous() for t in
+              (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, m.fc3.weight, m.fc3.bias, m.fc4.weight, m.fc4.bias)]
+        self.in_dim, self.hidden, self.act_dim = ws[0].shape[1], ws[0].shape[0], ws[6].shape[0]
+        h = ct.c_void_p()
+        rc = self.lib.swarm_policy_create(*[ct.c_void_p(w.data_ptr()) for w in ws], self.in_dim, self.hidden, self.act_dim,
+                                          self.device.index or 0, ct.byref(h))
+        if rc != 0:
+            raise RuntimeError("swarm_policy_create failed: " + self.lib.swarm_policy_last_error().decode())
+        self.close()
+        self.handle = h
+
+    def __call__(self, obs):
+        """obs [rows, in_dim] float32 on the device (contiguous) -> actions [rows, act_dim] float32."""
+        if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.device != self.device or obs.shape[-1] != self.in_dim:
+            raise ValueError("FusedPolicy expects a contiguous float32 [rows, %d] tensor on %s" % (self.in_dim, self.device))
+        rows = obs.numel() // self.in_dim
+        out = torch.empty((rows, self.act_dim), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.swarm_policy_forward(self.handle, obs.data_ptr(), rows, out.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError("swarm_policy_forward failed: " + self.lib.swarm_policy_last_error().decode())
+        return out
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.swarm_policy_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceReplay:

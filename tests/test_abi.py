@@ -36,6 +36,25 @@ def test_header_symbols_exported(lib):
     assert lib.swarm_abi_version() == ABI_VERSION
 
 
+def test_policy_header_symbols_exported(lib):
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "swarm_policy.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(swarm_policy_[a-z_]+)\s*\(", src)))
+    from marl_llm_amd._lib import POLICY_SYMBOLS
+    assert set(names) == set(POLICY_SYMBOLS), names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/swarm_policy.h but not exported"
+
+
+def test_policy_create_fails_loudly_without_a_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a HIP device")
+    w = (ctypes.c_float * (192 * 192))()
+    h = ctypes.c_void_p()
+    rc = lib.swarm_policy_create(*[ctypes.cast(w, ctypes.c_void_p)] * 8, 192, 180, 2, -1, ctypes.byref(h))
+    assert rc != 0 and b"no HIP device" in lib.swarm_policy_last_error()
+
+
 def test_config_struct_matches_header(lib):
     from marl_llm_amd._lib import SwarmConfig
     cfg = SwarmConfig()

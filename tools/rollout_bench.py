@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from marl_llm_amd.batched import SwarmBatch
-from marl_llm_amd.rollout import DeviceReplay, PolicyMLP, rollout
+from marl_llm_amd.rollout import DeviceReplay, FusedPolicy, PolicyMLP, rollout
 from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
 
 
@@ -52,6 +52,19 @@ def main():
     t_pol = timed(lambda k: with_policy(k))
     t_pol_bf16 = timed(lambda k: with_policy(k, autocast=True))
     t_full = timed(lambda k: with_policy(k, rep=replay, autocast=True))
+    fused = FusedPolicy(policy, device=sb.device)
+
+    def with_fused(k, rep=None):
+        state["obs"], _ = rollout(sb, fused, k, state["obs"], replay=rep, noise_scale=0.1)
+
+    def fused_only(k):
+        x = state["obs"].reshape(E * n_a, -1)
+        for _ in range(k):
+            fused(x)
+
+    t_fk = timed(fused_only)
+    t_fpol = timed(lambda k: with_fused(k))
+    t_ffull = timed(lambda k: with_fused(k, rep=replay))
     n = E * n_a
     print(f"{n_a} agents x {E} envs on one MI355X, device-resident (per step, agent-steps/s):")
     print(f"  batched device reset of all envs        {t_reset * 1e3:8.3f} ms")
@@ -59,6 +72,9 @@ def main():
     print(f"  + policy MLP fp32 + noise               {t_pol * 1e3:8.3f} ms   {n / t_pol / 1e6:9.1f} M")
     print(f"  + policy MLP bf16 autocast + noise      {t_pol_bf16 * 1e3:8.3f} ms   {n / t_pol_bf16 / 1e6:9.1f} M")
     print(f"  + replay push (obs, act, rew, next_obs) {t_full * 1e3:8.3f} ms   {n / t_full / 1e6:9.1f} M")
+    print(f"  fused MFMA policy kernel alone          {t_fk * 1e3:8.3f} ms   {n / t_fk / 1e6:9.1f} M rows/s")
+    print(f"  env + fused MFMA policy + noise         {t_fpol * 1e3:8.3f} ms   {n / t_fpol / 1e6:9.1f} M")
+    print(f"  + replay push                           {t_ffull * 1e3:8.3f} ms   {n / t_ffull / 1e6:9.1f} M")
     sb.close()
 
 
