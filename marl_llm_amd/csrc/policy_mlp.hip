@@ -45,138 +45,114 @@ struct MlpParams {
 
 __device__ __forceinline__ int feat_of(int mt, int reg, int h) { return 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
-// A workgroup = kWaves wavefronts x TPW row tiles of 32 rows each.  Per layer the packed weight fragments (72 KB for a
-// hidden layer) are copied once into LDS and read from there by every wave (ds_read_b128, lane-linear = conflict-free);
-// each fragment read feeds TPW MFMAs.  Without this the kernel is bound by streaming 233 KB of weights per 32 rows
-// through L2 -> L1 (measured 248 us for 262144 rows vs 136 us with the staging); weights per row drop by kWaves * TPW.
-template <int TPW>
-__device__ __forceinline__ void stage_weights(bf8 *wl, const bf8 *__restrict__ w, int n_frag)
-{
-    __syncthreads();                                                        // everyone is done with the previous layer's weights
-    for (int q = threadIdx.x; q < n_frag * 64; q += 64 * kWaves) wl[q] = w[q];
-    __syncthreads();
-}
+// A workgroup = kWaves wavefronts, one 32-row tile each.  The packed weights stream through LDS in CHUNKS of three feature
+// tiles (36 fragments = 36 KB; the output layer's 12 fragments are the last chunk), two LDS buffers: while the waves run
+// the MFMAs of chunk c out of one buffer, every thread already holds chunk c+1 in registers (9 x 16 B, global loads issued
+// before the MFMA loop) and writes it to the other buffer afterwards -- one barrier per chunk, the L2 latency of the weight
+// stream hidden behind the matrix cores.  (Measured at 262144 rows: weights straight from L2 per wave 248 us; whole layers
+// staged with the waves waiting 136 us, of which 47 us staging and 50 us observation loads.)
+// Biases: layer 1's initialise the accumulators; for the later layers the (padded) hidden feature kOne is held at 1.0 --
+// bias 1 / zero weights in layer 1, a 1.0 on the diagonal afterwards -- and the biases sit in that column of the packed
+// weights (bf16, as under torch.autocast), so no bias loads in the chain.
+constexpr int kChunkFrags = 3 * kKS;                                        // 36 fragments
+constexpr int kChunks = 7;                                                  // 2 per hidden layer + the output layer
+constexpr int kPre = kChunkFrags * 64 / (64 * kWaves);                      // 16-byte pieces per thread and chunk: 9
+constexpr int kSmemBytes = 2 * kChunkFrags * 64 * 16;                       // 72 KB
 
-template <int TPW>
-__device__ __forceinline__ void activate_pack(const f16v (&acc)[TPW][kMT], bf8 (&pk)[TPW][kMT][2])
-{
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int kt = 0; kt < kMT; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = acc[t][kt][8 * s + j];
-                    pk[t][kt][s][j] = (__bf16)fmaxf(v, 0.01f * v);       // leaky ReLU, slope 0.01 (networks.py:40-42)
-                }
-}
-
-// hidden layer l+1 from the packed activations of layer l; weights in LDS
-template <int TPW>
-__device__ __forceinline__ void hidden_layer(const bf8 *wl, const float *__restrict__ bias, bf8 (&pk)[TPW][kMT][2], int lane, int h)
-{
-    f16v acc[TPW][kMT];
-#pragma unroll
-    for (int mt = 0; mt < kMT; ++mt)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float bv = bias[feat_of(mt, reg, h)];
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t][mt][reg] = bv;
-        }
-#pragma unroll
-    for (int kt = 0; kt < kMT; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int mt = 0; mt < kMT; ++mt) {
-                const bf8 a = wl[(mt * kKS + kt * 2 + s) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pk[t][kt][s], acc[t][mt], 0, 0, 0);
-            }
-    activate_pack<TPW>(acc, pk);
-}
-
-template <int TPW>
-__global__ void __launch_bounds__(64 * kWaves)
+__global__ void __launch_bounds__(64 * kWaves, 2)
 k_policy_mlp(const MlpParams P, const float *__restrict__ obs, float *__restrict__ act)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    bf8 *wl = reinterpret_cast<bf8 *>(smem_raw);                            // [feature tile][k-step][lane]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf8 *const buf[2] = {reinterpret_cast<bf8 *>(smem_raw), reinterpret_cast<bf8 *>(smem_raw) + kChunkFrags * 64};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const long long row0 = ((long long)blockIdx.x * kWaves + wave) * (32 * TPW);      // first row of this wave
-    const bool wave_on = row0 < P.rows;                                     // idle waves still take part in the barriers
+    const long long row = ((long long)blockIdx.x * kWaves + wave) * 32 + r;
+    const bool wave_on = ((long long)blockIdx.x * kWaves + wave) * 32 < P.rows;     // idle waves still stage and take the barriers
 
-    bf8 pk[TPW][kMT][2];
-    stage_weights<TPW>(wl, P.w1, kMT * kKS);
-    if (wave_on) {   // layer 1: B fragments straight from the observation rows (natural k order)
-        f16v acc[TPW][kMT];
+    bf8 pre[kPre];
+    auto issue = [&](int c) {                                               // chunk c of the weight stream -> registers
+        const bf8 *w = c < 2 ? P.w1 + (size_t)c * kChunkFrags * 64 : c < 4 ? P.w2 + (size_t)(c - 2) * kChunkFrags * 64
+                     : c < 6 ? P.w3 + (size_t)(c - 4) * kChunkFrags * 64 : P.w4;
+        const int n = (c < 6 ? kChunkFrags : kKS) * 64;
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt)
+        for (int k = 0; k < kPre; ++k) { const int q = tid + k * 64 * kWaves; if (q < n) pre[k] = w[q]; }
+    };
+    auto commit = [&](int c) {                                              // registers -> LDS buffer of chunk c
+        const int n = (c < 6 ? kChunkFrags : kKS) * 64;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float bv = P.b1[feat_of(mt, reg, h)];
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[t][mt][reg] = bv;
-            }
-        const float *x[TPW];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const long long row = row0 + 32 * t + r;
-            x[t] = obs + (size_t)(row < P.rows ? row : P.rows - 1) * P.in_dim;
-        }
+        for (int k = 0; k < kPre; ++k) { const int q = tid + k * 64 * kWaves; if (q < n) buf[c & 1][q] = pre[k]; }
+    };
+
+    issue(0);
+    // the 12 B fragments of layer 1, straight from the observation row (natural k order); later `pk` holds the packed
+    // activations of the previous layer (k-step = 2 * feature tile + s)
+    bf8 pk[kKS];
+    f16v acc[kMT];
+    if (wave_on) {
+        const float *x = obs + (size_t)(row < P.rows ? row : P.rows - 1) * P.in_dim;
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) {
             const int k0 = 16 * ks + 8 * h;
-            bf8 b[TPW];
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (k0 < P.in_dim) lo = *reinterpret_cast<const float4 *>(x + k0);              // in_dim is a multiple of 4
+            if (k0 + 4 < P.in_dim) hi = *reinterpret_cast<const float4 *>(x + k0 + 4);
+            pk[ks][0] = (__bf16)lo.x; pk[ks][1] = (__bf16)lo.y; pk[ks][2] = (__bf16)lo.z; pk[ks][3] = (__bf16)lo.w;
+            pk[ks][4] = (__bf16)hi.x; pk[ks][5] = (__bf16)hi.y; pk[ks][6] = (__bf16)hi.z; pk[ks][7] = (__bf16)hi.w;
+        }
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-                if (k0 < P.in_dim) lo = *reinterpret_cast<const float4 *>(x[t] + k0);          // in_dim is a multiple of 4
-                if (k0 + 4 < P.in_dim) hi = *reinterpret_cast<const float4 *>(x[t] + k0 + 4);
-                b[t][0] = (__bf16)lo.x; b[t][1] = (__bf16)lo.y; b[t][2] = (__bf16)lo.z; b[t][3] = (__bf16)lo.w;
-                b[t][4] = (__bf16)hi.x; b[t][5] = (__bf16)hi.y; b[t][6] = (__bf16)hi.z; b[t][7] = (__bf16)hi.w;
-            }
+        for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt) {
-                const bf8 a = wl[(mt * kKS + ks) * 64 + lane];
+            for (int reg = 0; reg < 16; ++reg) acc[mt][reg] = P.b1[feat_of(mt, reg, h)];
+    }
+    commit(0);
+    __syncthreads();
+
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[t][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[t], acc[t][mt], 0, 0, 0);
+    for (int c = 0; c < kChunks; ++c) {
+        if (c + 1 < kChunks) issue(c + 1);
+        const bf8 *wl = buf[c & 1];
+        if (wave_on) {
+            if (c < 6) {
+                const int half = c & 1;
+#pragma unroll
+                for (int ks = 0; ks < kKS; ++ks)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        acc[3 * half + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(m * kKS + ks) * 64 + lane], pk[ks], acc[3 * half + m], 0, 0, 0);
+                if (half == 1) {                                            // layer complete: leaky ReLU (slope 0.01, networks.py:40-42), pack
+#pragma unroll
+                    for (int kt = 0; kt < kMT; ++kt)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = acc[kt][8 * s + j];
+                                pk[2 * kt + s][j] = (__bf16)fmaxf(v, 0.01f * v);
+                            }
+#pragma unroll
+                    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) acc[mt][reg] = 0.0f;
+                }
+            } else {
+                // output layer: one feature tile; action k is accumulator register k of the lower lane half (row = reg, h = 0)
+                f16v o = acc[0];                                            // zeros
+#pragma unroll
+                for (int ks = 0; ks < kKS; ++ks) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks * 64 + lane], pk[ks], o, 0, 0, 0);
+                if (h == 0 && row < P.rows) {
+                    float *y = act + (size_t)row * P.act_dim;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < P.act_dim) y[k] = tanhf(o[k]);              // networks.py:43 tanh output
+                }
             }
         }
-        activate_pack<TPW>(acc, pk);
-    }
-    stage_weights<TPW>(wl, P.w2, kMT * kKS);
-    if (wave_on) hidden_layer<TPW>(wl, P.b2, pk, lane, h);
-    stage_weights<TPW>(wl, P.w3, kMT * kKS);
-    if (wave_on) hidden_layer<TPW>(wl, P.b3, pk, lane, h);
-    stage_weights<TPW>(wl, P.w4, kKS);
-    if (!wave_on) return;
-    // output layer: one feature tile; action k is accumulator register k of the lower lane half (row = reg for reg < 4, h = 0)
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        f16v o;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) o[reg] = P.b4[feat_of(0, reg, h) & 31];
-#pragma unroll
-        for (int kt = 0; kt < kMT; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(kt * 2 + s) * 64 + lane], pk[t][kt][s], o, 0, 0, 0);
-        const long long row = row0 + 32 * t + r;
-        if (h == 0 && row < P.rows) {
-            float *y = act + (size_t)row * P.act_dim;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < P.act_dim) y[k] = tanhf(o[k]);                      // networks.py:43 tanh output
+        if (c + 1 < kChunks) {
+            commit(c + 1);                                                  // the other buffer: last read in step c - 1, behind the barrier
+            __syncthreads();
         }
     }
 }
-
-constexpr int kSmemBytes = kMT * kKS * 64 * 16;                             // one hidden layer's fragments: 72 KB
 
 uint16_t bf16_rne(float f)
 {
@@ -208,8 +184,8 @@ int swarm_policy_create(const float *w1, const float *b1, const float *w2, const
     if (!out) return SWARM_POLICY_ERR_INVALID;
     *out = nullptr;
     if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4) { g_policy_error = "swarm_policy_create: null weight pointer"; return SWARM_POLICY_ERR_INVALID; }
-    if (in_dim < 4 || in_dim > kKP || (in_dim & 3) || hidden < 1 || hidden > kKP || act_dim < 1 || act_dim > 4) {
-        g_policy_error = "swarm_policy_create: supported shapes are in_dim <= 192 (multiple of 4), hidden <= 192, act_dim <= 4";
+    if (in_dim < 4 || in_dim > kKP || (in_dim & 3) || hidden < 1 || hidden >= kKP || act_dim < 1 || act_dim > 4) {
+        g_policy_error = "swarm_policy_create: supported shapes are in_dim <= 192 (multiple of 4), hidden <= 191, act_dim <= 4";
         return SWARM_POLICY_ERR_INVALID;
     }
     int ndev = 0;
@@ -240,12 +216,24 @@ int swarm_policy_create(const float *w1, const float *b1, const float *w2, const
                         dst[((size_t)(mt * kKS + ks) * 64 + lane) * 8 + j] = bf16_rne(v);
                     }
     };
+    // The padded hidden feature `one` carries the constant 1.0 through the chain: layer 1 produces it (zero weights, bias 1),
+    // the later layers copy it (1.0 on the diagonal) and read their biases from its weight column.
+    const int one = hidden;
+    auto with_bias = [&](const float *w, const float *b, int n_out_feat, bool keep_one) {
+        std::vector<float> a((size_t)kKP * kKP, 0.0f);                      // [out][in], in padded to kKP
+        for (int o = 0; o < n_out_feat; ++o) {
+            for (int k = 0; k < hidden; ++k) a[(size_t)o * kKP + k] = w[(size_t)o * hidden + k];
+            a[(size_t)o * kKP + one] = b[o];
+        }
+        if (keep_one) a[(size_t)one * kKP + one] = 1.0f;
+        return a;
+    };
     pack(wp, w1, hidden, in_dim, kMT, true);
-    pack(wp + n_hid, w2, hidden, hidden, kMT, false);
-    pack(wp + 2 * n_hid, w3, hidden, hidden, kMT, false);
-    pack(wp + 3 * n_hid, w4, act_dim, hidden, 1, false);
-    for (int k = 0; k < hidden; ++k) { bp[k] = b1[k]; bp[kKP + k] = b2[k]; bp[2 * kKP + k] = b3[k]; }
-    for (int k = 0; k < act_dim; ++k) bp[3 * kKP + k] = b4[k];
+    { const std::vector<float> a = with_bias(w2, b2, hidden, true); pack(wp + n_hid, a.data(), kKP, kKP, kMT, false); }
+    { const std::vector<float> a = with_bias(w3, b3, hidden, true); pack(wp + 2 * n_hid, a.data(), kKP, kKP, kMT, false); }
+    { const std::vector<float> a = with_bias(w4, b4, act_dim, false); pack(wp + 3 * n_hid, a.data(), kKP, kKP, 1, false); }
+    for (int k = 0; k < hidden; ++k) bp[k] = b1[k];
+    bp[one] = 1.0f;
 
     swarm_policy *p = new (std::nothrow) swarm_policy;
     if (!p) return SWARM_POLICY_ERR_INVALID;
@@ -285,16 +273,13 @@ int swarm_policy_forward(swarm_policy_t *p, const float *obs, int64_t rows, floa
     if (hipSetDevice(p->device) != hipSuccess) { g_policy_error = "swarm_policy_forward: hipSetDevice failed"; return SWARM_POLICY_ERR_HIP; }
     MlpParams q = p->p;
     q.rows = rows;
-    // one 32-row tile per wave: 204 VGPRs and 72 KB of LDS -> two workgroups (8 waves) per CU.  Two tiles per wave (each
-    // fragment read feeding two MFMAs) needs 400 VGPRs, i.e. one wave per SIMD, and measured slower (159 vs 136 us at
-    // 262144 rows): the template parameter is kept for that experiment only.
     const long long per_block = (long long)kWaves * 32;
     const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
     if (!p->smem_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
         p->smem_set = true;
     }
-    hipLaunchKernelGGL(k_policy_mlp<1>, dim3(grid), dim3(64 * kWaves), kSmemBytes, static_cast<hipStream_t>(stream), q, obs, act);
+    hipLaunchKernelGGL(k_policy_mlp, dim3(grid), dim3(64 * kWaves), kSmemBytes, static_cast<hipStream_t>(stream), q, obs, act);
     const hipError_t e = hipGetLastError();
     (void)hipSetDevice(prev);
     if (e != hipSuccess) { g_policy_error = std::string("swarm_policy_forward: ") + hipGetErrorString(e); return SWARM_POLICY_ERR_HIP; }
