@@ -61,7 +61,7 @@ extern "C" {
 
 #define SWARM_ABI_VERSION 2
 
-enum { SWARM_F32 = 0, SWARM_F64 = 1 };
+enum { SWARM_F32 = 0, SWARM_F64 = 1, SWARM_BF16 = 2 };
 
 enum {
     SWARM_OK = 0,
@@ -83,7 +83,9 @@ typedef struct swarm_config {
     int32_t is_boundary;            /* 1 = walls (assembly.py:99-103), 0 = periodic */
     int32_t with_self_state;        /* is_con_self_state */
     int32_t with_prior;             /* training_method == 'llm_rl': compute a_prior (assembly.py:605-624) */
-    int32_t obs_dtype;              /* SWARM_F32 (product) or SWARM_F64 (bit-exact parity mode) */
+    int32_t obs_dtype;              /* SWARM_F32 (product), SWARM_F64 (bit-exact parity mode) or SWARM_BF16 (obs and a_prior as
+                                     * bfloat16 = the f32 value rounded to nearest-even: half the rollout's bytes, feeds the bf16
+                                     * policy kernel of swarm_policy.h directly) */
     int32_t device;                 /* HIP device ordinal, -1 = current */
     int32_t debug_flags;            /* bit 0: force every exact (fp64) fallback path of the fp32 pre-filters; bit 1: disable the lattice path;
                                      * bits 8..15: diagnostics (tools/ablate.py) */

@@ -32,6 +32,11 @@ void swarm_policy_destroy(swarm_policy_t *p);
  * densely packed; stream is a hipStream_t (NULL: the default stream).  Asynchronous. */
 int  swarm_policy_forward(swarm_policy_t *p, const float *obs, int64_t rows, float *act, void *stream);
 
+/* The same with bfloat16 observation rows (the env's SWARM_BF16 output, swarm_env.h): each 16-byte load is one MFMA
+ * operand fragment, no conversion.  in_dim must be a multiple of 8 (16-byte aligned rows).  Identical results to
+ * swarm_policy_forward on the same values held in float32. */
+int  swarm_policy_forward_bf16(swarm_policy_t *p, const void *obs_bf16, int64_t rows, float *act, void *stream);
+
 const char *swarm_policy_last_error(void);
 
 #ifdef __cplusplus

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F32, F64, SwarmConfig, SwarmError, check
+from ._lib import BF16, F32, F64, SwarmConfig, SwarmError, check
 
 
 def _ptr(t):
@@ -34,9 +34,9 @@ class SwarmBatch:
         cfg.n_env, cfg.n_agents, cfg.n_cells_max = int(n_env), int(n_agents), int(n_cells_max)
         cfg.topo_nei_max, cfg.num_obs_grid_max, cfg.num_occupied_grid_max = int(topo), int(g_max), int(occ_max)
         cfg.is_boundary, cfg.with_self_state, cfg.with_prior = int(bool(is_boundary)), int(bool(with_self)), int(bool(with_prior))
-        if obs_dtype not in (torch.float32, torch.float64):
-            raise SwarmError("obs_dtype must be torch.float32 or torch.float64")
-        cfg.obs_dtype = F64 if obs_dtype == torch.float64 else F32
+        if obs_dtype not in (torch.float32, torch.float64, torch.bfloat16):
+            raise SwarmError("obs_dtype must be torch.float32, torch.float64 or torch.bfloat16")
+        cfg.obs_dtype = F64 if obs_dtype == torch.float64 else BF16 if obs_dtype == torch.bfloat16 else F32
         cfg.device = dev_index
         cfg.debug_flags = int(debug_flags)
         cfg.d_sen, cfg.r_avoid, cfg.size_a = float(d_sen), float(r_avoid), float(size_a)

@@ -59,8 +59,9 @@ constexpr int kChunks = 7;                                                  // 2
 constexpr int kPre = kChunkFrags * 64 / (64 * kWaves);                      // 16-byte pieces per thread and chunk: 9
 constexpr int kSmemBytes = 2 * kChunkFrags * 64 * 16;                       // 72 KB
 
+template <bool IN_BF16>
 __global__ void __launch_bounds__(64 * kWaves, 2)
-k_policy_mlp(const MlpParams P, const float *__restrict__ obs, float *__restrict__ act)
+k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict__ act)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     bf8 *const buf[2] = {reinterpret_cast<bf8 *>(smem_raw), reinterpret_cast<bf8 *>(smem_raw) + kChunkFrags * 64};
@@ -89,10 +90,19 @@ k_policy_mlp(const MlpParams P, const float *__restrict__ obs, float *__restrict
     bf8 pk[kKS];
     f16v acc[kMT];
     if (wave_on) {
-        const float *x = obs + (size_t)(row < P.rows ? row : P.rows - 1) * P.in_dim;
+        const size_t xoff = (size_t)(row < P.rows ? row : P.rows - 1) * P.in_dim;
+        const float *x = static_cast<const float *>(obs_) + xoff;
+        const __bf16 *xb = static_cast<const __bf16 *>(obs_) + xoff;
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) {
             const int k0 = 16 * ks + 8 * h;
+            if constexpr (IN_BF16) {                                        // the fragment as it lies in memory (in_dim % 8 == 0)
+                bf8 z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
+                pk[ks] = k0 < P.in_dim ? *reinterpret_cast<const bf8 *>(xb + k0) : z;
+                continue;
+            }
             float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
             if (k0 < P.in_dim) lo = *reinterpret_cast<const float4 *>(x + k0);              // in_dim is a multiple of 4
             if (k0 + 4 < P.in_dim) hi = *reinterpret_cast<const float4 *>(x + k0 + 4);
@@ -264,9 +274,10 @@ void swarm_policy_destroy(swarm_policy_t *p)
     delete p;
 }
 
-int swarm_policy_forward(swarm_policy_t *p, const float *obs, int64_t rows, float *act, void *stream)
+static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int64_t rows, float *act, void *stream)
 {
     if (!p || !obs || !act || rows < 0) { g_policy_error = "swarm_policy_forward: bad argument"; return SWARM_POLICY_ERR_INVALID; }
+    if (in_bf16 && (p->in_dim & 7)) { g_policy_error = "swarm_policy_forward_bf16: in_dim must be a multiple of 8"; return SWARM_POLICY_ERR_INVALID; }
     if (rows == 0) return SWARM_POLICY_OK;
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -276,14 +287,26 @@ int swarm_policy_forward(swarm_policy_t *p, const float *obs, int64_t rows, floa
     const long long per_block = (long long)kWaves * 32;
     const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
     if (!p->smem_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
         p->smem_set = true;
     }
-    hipLaunchKernelGGL(k_policy_mlp, dim3(grid), dim3(64 * kWaves), kSmemBytes, static_cast<hipStream_t>(stream), q, obs, act);
+    if (in_bf16) hipLaunchKernelGGL(k_policy_mlp<true>, dim3(grid), dim3(64 * kWaves), kSmemBytes, static_cast<hipStream_t>(stream), q, obs, act);
+    else hipLaunchKernelGGL(k_policy_mlp<false>, dim3(grid), dim3(64 * kWaves), kSmemBytes, static_cast<hipStream_t>(stream), q, obs, act);
     const hipError_t e = hipGetLastError();
     (void)hipSetDevice(prev);
     if (e != hipSuccess) { g_policy_error = std::string("swarm_policy_forward: ") + hipGetErrorString(e); return SWARM_POLICY_ERR_HIP; }
     return SWARM_POLICY_OK;
+}
+
+int swarm_policy_forward(swarm_policy_t *p, const float *obs, int64_t rows, float *act, void *stream)
+{
+    return policy_forward(p, obs, false, rows, act, stream);
+}
+
+int swarm_policy_forward_bf16(swarm_policy_t *p, const void *obs_bf16, int64_t rows, float *act, void *stream)
+{
+    return policy_forward(p, obs_bf16, true, rows, act, stream);
 }
 
 }  // extern "C"

@@ -101,6 +101,13 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 template <typename T> struct Pair;
 template <> struct Pair<float>  { typedef float2 type; };
 template <> struct Pair<double> { typedef double2 type; };
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2v;
+template <> struct Pair<__bf16> { typedef bf2v type; };
+
+// output conversion of an exact fp64 value: one rounding for f64 / f32; bf16 = the f32 value rounded again (RNE), i.e. what a
+// consumer gets from `obs_f32.to(bfloat16)`
+template <typename OT> __device__ __forceinline__ OT to_out(double v) { return (OT)v; }
+template <> __device__ __forceinline__ __bf16 to_out<__bf16>(double v) { return (__bf16)(float)v; }
 
 __device__ __forceinline__ void wrap_rel(double &x, double &y, double wh, double hh)
 {   // CPP:700-715
@@ -403,7 +410,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     avx /= cnt; avy /= cnt;
                     qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
                 }
-                OT2 o; o.x = (OT)clamp_ref(qx, -1.0, 1.0); o.y = (OT)clamp_ref(qy, -1.0, 1.0);
+                OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
                 reinterpret_cast<OT2 *>(a_prior)[(size_t)e * n_a + i] = o;
             }
         }
@@ -1282,7 +1289,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 }
                 double a = ma - sa_, b = mb - sb_;
                 if (P.periodic && is_nei && half == 0) wrap_rel(a, b, P.w_half, P.h_half);      // CPP:79 relative position, wrapped
-                OT2 o; o.x = (OT)a; o.y = (OT)b;
+                OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
                 out[(size_t)r * PPR + q] = o;
                 q += dq; r += dr;
                 if (q >= HP) { q -= HP; ++r; }
@@ -1311,7 +1318,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const int c = srow[q];
                     double a = 0.0, b = 0.0;
                     if (c >= 0) { const double2 g = gr[c]; a = g.x - qx; b = g.y - qy; }
-                    OT2 o; o.x = (OT)a; o.y = (OT)b;
+                    OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
                     orow[q] = o;
                 }
             }
@@ -1329,7 +1336,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         const int c = sidx[(size_t)tr * P.g_stride + q];
                         double a = 0.0, b = 0.0;
                         if (c >= 0) { const double2 g = gr[c]; a = g.x - sp[tr]; b = g.y - sp[AG + tr]; }
-                        OT2 o; o.x = (OT)a; o.y = (OT)b;
+                        OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
                         out[(size_t)r * PPR + HP + q] = o;
                     }
                 }
@@ -1652,7 +1659,7 @@ struct swarm_env {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool have_cells, have_state, observed;
-    int attr_smem[4];
+    int attr_smem[6];
     std::vector<char> cells_set;
     std::string err;
     // device buffers
@@ -1826,7 +1833,7 @@ int launch_t(swarm_env *h, const void *action, int act_f64, void *obs, float *re
 #ifdef SWARM_EXTRA_SMEM
     smem += SWARM_EXTRA_SMEM;                            // occupancy experiments only
 #endif
-    int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : 0)];   // raise the dynamic-LDS cap once per size
+    int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : sizeof(OT) == 2 ? 4 : 0)];   // raise the dynamic-LDS cap once per instantiation
     if (attr < smem) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = smem;
@@ -1842,13 +1849,15 @@ template <int NPAD>
 int launch_n(swarm_env *h, bool do_step, const void *action, int act_f64, void *obs, float *reward, uint8_t *done,
              void *a_prior)
 {
-    const bool f64 = h->cfg.obs_dtype == SWARM_F64;
+    const int dt = h->cfg.obs_dtype;
     if (do_step) {
-        return f64 ? launch_t<NPAD, double, true>(h, action, act_f64, obs, reward, done, a_prior)
-                   : launch_t<NPAD, float, true>(h, action, act_f64, obs, reward, done, a_prior);
+        return dt == SWARM_F64 ? launch_t<NPAD, double, true>(h, action, act_f64, obs, reward, done, a_prior)
+             : dt == SWARM_BF16 ? launch_t<NPAD, __bf16, true>(h, action, act_f64, obs, reward, done, a_prior)
+                                : launch_t<NPAD, float, true>(h, action, act_f64, obs, reward, done, a_prior);
     }
-    return f64 ? launch_t<NPAD, double, false>(h, action, act_f64, obs, reward, done, a_prior)
-               : launch_t<NPAD, float, false>(h, action, act_f64, obs, reward, done, a_prior);
+    return dt == SWARM_F64 ? launch_t<NPAD, double, false>(h, action, act_f64, obs, reward, done, a_prior)
+         : dt == SWARM_BF16 ? launch_t<NPAD, __bf16, false>(h, action, act_f64, obs, reward, done, a_prior)
+                            : launch_t<NPAD, float, false>(h, action, act_f64, obs, reward, done, a_prior);
 }
 
 int launch(swarm_env *h, bool do_step, const void *action, int act_f64, void *obs, float *reward, uint8_t *done,
@@ -1896,7 +1905,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     if (cfg->topo_nei_max < 1 || cfg->topo_nei_max > kTopoMax) return fail(nullptr, SWARM_ERR_INVALID, "topo_nei_max must be in [1, 6]");
     if (cfg->num_obs_grid_max < 2 || cfg->num_obs_grid_max > 4096) return fail(nullptr, SWARM_ERR_INVALID, "num_obs_grid_max must be in [2, 4096]");
     if (cfg->num_occupied_grid_max < 2) return fail(nullptr, SWARM_ERR_INVALID, "num_occupied_grid_max must be >= 2");
-    if (cfg->obs_dtype != SWARM_F32 && cfg->obs_dtype != SWARM_F64) return fail(nullptr, SWARM_ERR_INVALID, "obs_dtype must be SWARM_F32 or SWARM_F64");
+    if (cfg->obs_dtype != SWARM_F32 && cfg->obs_dtype != SWARM_F64 && cfg->obs_dtype != SWARM_BF16) return fail(nullptr, SWARM_ERR_INVALID, "obs_dtype must be SWARM_F32, SWARM_F64 or SWARM_BF16");
     if (!(cfg->d_sen > 0) || !(cfg->r_avoid > 0) || !(cfg->dt > 0)) return fail(nullptr, SWARM_ERR_INVALID, "d_sen, r_avoid, dt must be positive");
 
     int ndev = 0;
@@ -2313,7 +2322,7 @@ double swarm_step_algorithmic_bytes(const swarm_env_t *h)
     if (!h) return 0.0;
     // Per agent-step: action 2*4 r, state p/dp 4*8 r + 4*8 w (fp64 here), obs D*sizeof w, reward 4 + done 1 +
     // prior 2*sizeof w; per env: target cells 2*n_g_max*8 r.  (with this build's dtypes.)
-    const double so = h->cfg.obs_dtype == SWARM_F64 ? 8.0 : 4.0;
+    const double so = h->cfg.obs_dtype == SWARM_F64 ? 8.0 : h->cfg.obs_dtype == SWARM_BF16 ? 2.0 : 4.0;
     const double per_agent = 8.0 + 64.0 + h->kp.obs_dim * so + 5.0 + 2.0 * so;
     return (double)h->cfg.n_env * (h->cfg.n_agents * per_agent + 2.0 * h->kp.ng_max * 8.0);
 }

@@ -63,13 +63,15 @@ class FusedPolicy:
         self.handle = h
 
     def __call__(self, obs):
-        """obs [rows, in_dim] float32 on the device (contiguous) -> actions [rows, act_dim] float32."""
-        if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.device != self.device or obs.shape[-1] != self.in_dim:
-            raise ValueError("FusedPolicy expects a contiguous float32 [rows, %d] tensor on %s" % (self.in_dim, self.device))
+        """obs [rows, in_dim] float32 or bfloat16 on the device (contiguous) -> actions [rows, act_dim] float32."""
+        if (obs.dtype not in (torch.float32, torch.bfloat16) or not obs.is_contiguous() or obs.device != self.device
+                or obs.shape[-1] != self.in_dim):
+            raise ValueError("FusedPolicy expects a contiguous float32 / bfloat16 [rows, %d] tensor on %s" % (self.in_dim, self.device))
         rows = obs.numel() // self.in_dim
         out = torch.empty((rows, self.act_dim), dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.swarm_policy_forward(self.handle, obs.data_ptr(), rows, out.data_ptr(), stream)
+        fwd = self.lib.swarm_policy_forward_bf16 if obs.dtype == torch.bfloat16 else self.lib.swarm_policy_forward
+        rc = fwd(self.handle, obs.data_ptr(), rows, out.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError("swarm_policy_forward failed: " + self.lib.swarm_policy_last_error().decode())
         return out
@@ -139,7 +141,7 @@ def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, 
     rews = torch.zeros(steps, device=obs.device)
     for t in range(steps):
         x = obs.reshape(E * N, D)
-        if x.dtype != torch.float32:
+        if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and isinstance(policy, FusedPolicy)):
             x = x.float()
         act = policy(x)
         if epsilon > 0 and float(torch.rand((), device=obs.device, generator=generator)) < epsilon:   # agents.py:89-91

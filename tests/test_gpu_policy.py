@@ -108,3 +108,58 @@ def test_rollout_with_fused_policy(shapes=None):
     obs2, rews = rollout(sb, f, 5, obs)
     assert obs2.shape == (E, n_a, 192) and torch.isfinite(obs2).all() and rews.shape == (5,)
     sb.close()
+
+
+def test_bf16_observation_rows_give_identical_actions():
+    """swarm_policy_forward_bf16 on bf16 rows == swarm_policy_forward on the same values held in float32 (the fp32 path
+    rounds its input to bf16 first, so the MFMA operands are bit-identical)."""
+    import torch
+    from marl_llm_amd.rollout import FusedPolicy, PolicyMLP
+    torch.manual_seed(11)
+    f = FusedPolicy(PolicyMLP(192, 2, 180).cuda())
+    xb = (torch.randn(5000, 192, device="cuda") * 0.8).to(torch.bfloat16).contiguous()
+    assert torch.equal(f(xb), f(xb.float().contiguous()))
+    with pytest.raises(RuntimeError):                     # 188-wide bf16 rows are not 16-byte aligned
+        FusedPolicy(PolicyMLP(188, 2, 180).cuda())(torch.zeros(4, 188, device="cuda", dtype=torch.bfloat16))
+
+
+def test_bf16_env_output_and_rollout():
+    """obs_dtype=bfloat16: the env's obs / a_prior are the float32 outputs rounded to nearest-even bf16, bit for bit; the
+    bf16 rows feed the fused policy directly in a device-resident rollout."""
+    import torch
+    from marl_llm_amd.batched import SwarmBatch
+    from marl_llm_amd.rollout import DeviceReplay, FusedPolicy, PolicyMLP, rollout
+    from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
+    from marl_llm_amd.synth import synthetic_batch
+    shapes = synthetic_shape_set()
+    n_a, E = 64, 24
+    sy = synthetic_batch(E, n_a, shapes, seed=4, assembled_fraction=0.5)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=r_avoid_for(n_a, shapes),
+                        obs_dtype=dt, device="cuda:0")
+        sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"]); sb.set_state(sy["p"], sy["dp"])
+        o0 = sb.observe().clone()
+        act = torch.zeros((E, n_a, 2), device="cuda")
+        for _ in range(3):
+            o, r, d, pri = sb.step(act)
+            act = pri.float()
+        outs[dt] = (o0, o.clone(), pri.clone(), r.clone(), sb)
+    f32, b16 = outs[torch.float32], outs[torch.bfloat16]
+    assert b16[0].dtype == torch.bfloat16 and b16[2].dtype == torch.bfloat16
+    assert torch.equal(b16[0], f32[0].to(torch.bfloat16))
+    # the trajectories stay identical only while the fed-back prior is identical: compare the first step's outputs
+    f32[4].set_state(sy["p"], sy["dp"]); f32[4].observe()
+    b16[4].set_state(sy["p"], sy["dp"]); b16[4].observe()
+    z = torch.zeros((E, n_a, 2), device="cuda")
+    of, rf, _, pf = f32[4].step(z)
+    ob, rb, _, pb = b16[4].step(z)
+    assert torch.equal(ob, of.to(torch.bfloat16)) and torch.equal(pb, pf.to(torch.bfloat16)) and torch.equal(rb, rf)
+    sb = b16[4]
+    torch.manual_seed(1)
+    pol = FusedPolicy(PolicyMLP(192, 2, 180).cuda())
+    rep = DeviceReplay(4 * E * n_a, 192, 2, "cuda", obs_dtype=torch.bfloat16)
+    obs2, rews = rollout(sb, pol, 4, ob, replay=rep, noise_scale=0.1)
+    assert obs2.dtype == torch.bfloat16 and len(rep) == 4 * E * n_a and torch.isfinite(rews).all()
+    for x in outs.values():
+        x[4].close()

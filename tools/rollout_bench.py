@@ -75,6 +75,28 @@ def main():
     print(f"  fused MFMA policy kernel alone          {t_fk * 1e3:8.3f} ms   {n / t_fk / 1e6:9.1f} M rows/s")
     print(f"  env + fused MFMA policy + noise         {t_fpol * 1e3:8.3f} ms   {n / t_fpol / 1e6:9.1f} M")
     print(f"  + replay push                           {t_ffull * 1e3:8.3f} ms   {n / t_ffull / 1e6:9.1f} M")
+    # the same with bfloat16 observation rows end to end (env output, policy input, replay storage)
+    sb.close()
+    sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=ng_max, r_avoid=r_avoid_for(n_a, shapes), obs_dtype=torch.bfloat16)
+    sb.set_shapes(shapes)
+    state["obs"] = sb.reset(seed=226)
+    a0 = torch.zeros((E, n_a, 2), device=sb.device)
+    for _ in range(50):
+        state["obs"], _, _, pri = sb.step(a0)
+        a0 = pri.float()
+    replay16 = DeviceReplay(capacity_rows=8 * E * n_a, obs_dim=sb.obs_dim, act_dim=2, device=sb.device, obs_dtype=torch.bfloat16)
+
+    def env16(k):
+        a = a0
+        for _ in range(k):
+            a = sb.step(a)[3].float()
+
+    t_e16 = timed(env16)
+    t_f16 = timed(lambda k: with_fused(k))
+    t_f16r = timed(lambda k: with_fused(k, rep=replay16))
+    print(f"  bf16 rows: env step only                {t_e16 * 1e3:8.3f} ms   {n / t_e16 / 1e6:9.1f} M")
+    print(f"  bf16 rows: env + fused policy + noise   {t_f16 * 1e3:8.3f} ms   {n / t_f16 / 1e6:9.1f} M")
+    print(f"  bf16 rows: + replay push                {t_f16r * 1e3:8.3f} ms   {n / t_f16r / 1e6:9.1f} M")
     sb.close()
 
 
