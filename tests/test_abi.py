@@ -38,7 +38,7 @@ def test_header_symbols_exported(lib):
 
 def test_policy_header_symbols_exported(lib):
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "swarm_policy.h")).read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(swarm_policy_[a-z_]+)\s*\(", src)))
+    names = sorted(set(re.findall(r"\b(swarm_policy_[a-z0-9_]+)\s*\(", src)))
     from marl_llm_amd._lib import POLICY_SYMBOLS
     assert set(names) == set(POLICY_SYMBOLS), names
     for n in names:
