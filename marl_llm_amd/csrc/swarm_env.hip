@@ -9,11 +9,16 @@
 //
 // Mapping: lane = agent.  NPAD (agents per env rounded up to a power of two, 8..256) is a template
 // parameter; a 64-wide wavefront holds 64/NPAD whole environments when NPAD < 64, and an environment
-// of 128/256 agents is a workgroup of 2/4 wavefronts.  Per-env data that every agent re-reads (target
-// cells, agent positions/velocities) is staged once in LDS and read with wave-uniform addresses
-// (LDS broadcast).  Per-cell "which agents are within r_avoid/2" masks come straight from wavefront
-// ballots.  The observation block of an environment is streamed out with consecutive lanes writing
-// consecutive addresses (the rows of one env are contiguous in HBM).
+// of 128/256 agents takes 2/4 wavefronts.  A workgroup holds WPE copies ("splits") of its agent threads
+// that share the env's LDS footprint: sequential per-agent work (forces, prior, ordered neighbour
+// insertion, reward decision) runs on one split each, everything else is dealt over all of them.
+// Agent positions / velocities live in LDS and are read with wave-uniform addresses (LDS broadcast).
+// Target cells: when they form a lattice (the reference's tiled shapes always do) the sensed / covered /
+// nearest-cell queries walk lattice ROWS with bit operations on row masks and need no coordinates; the
+// exact fp64 coordinates are gathered from an interleaved copy in global memory only where a value or an
+// exact tie-break needs them.  Arbitrary cell sets take an fp32 pre-filter scan with exact fp64 fallback.
+// The observation block of an environment is streamed out with consecutive lanes writing consecutive
+// addresses (the rows of one env are contiguous in HBM).  DESIGN.md section 3 has the phase list.
 //
 // Numerics: everything that decides an index, a flag, the state or the reward is IEEE double in the
 // reference's operation order; this file MUST be compiled with -ffp-contract=off (the reference is
