@@ -1046,58 +1046,61 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     __syncthreads();
     EXIT_AT(7);
-    // (2) emit: every split walks the words in order to carry the running rank / slot counters; it writes the
-    // slots of its own words.
+    // (2) emit: the kept list of an agent is cut into WPE contiguous RANK ranges, one per split.  Each lane walks its
+    // own range bit by bit with a lane-private word pointer, so a wave's trip count is the longest range of any lane
+    // (n_kept / WPE) -- not, as with words dealt over the splits, the sum over words of the fullest lane's count.
     {
         short *row = sidx + (size_t)at * P.g_stride;
         for (int rep = 0, reps = REPS(11); rep < reps; ++rep) {
         FENCE();
-        int prefix = 0, sbase = 0;
-        if (!any_sub) {
+        const int per = (n_kept + WPE - 1) / WPE;
+        const int k0 = sx * per < n_kept ? sx * per : n_kept;
+        const int k1 = k0 + per < n_kept ? k0 + per : n_kept;
+        // the word holding rank k0 and the number of kept bits before k0 inside it
+        int ww = 0, within = 0;
+        {
+            int prefix = 0; bool found = false;
             for (int w = 0; w < W; ++w) {
-                if (mine(w)) {
-                    unsigned it = sbits[w * AG + at];
-                    int s = prefix;
-                    while (it) {                                   // up to 4 kept bits per trip
+                const int cnt = pc[w * AG + at];
+                const bool here = !found && prefix + cnt > k0;
+                ww = here ? w : ww; within = here ? k0 - prefix : within;
+                found = found || here;
+                prefix += cnt;
+            }
+        }
+        unsigned it = k0 < k1 ? sbits[ww * AG + at] : 0u;
+        {   // drop the `within` lowest set bits: position of the within-th set bit by a binary search on popcounts
+            int p = 0, left = within;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const bool has = it != 0;
-                            const int b = has ? __ffs(it) - 1 : 0;
-                            it &= it - 1;                          // 0 stays 0
-                            if (has) row[s] = (short)(w * 32 + b);
-                            s += has ? 1 : 0;
-                        }
-                    }
-                }
-                prefix += pc[w * AG + at];
+            for (int sh = 16; sh >= 1; sh >>= 1) {
+                const int c = __popc((it >> p) & ((1u << sh) - 1u));
+                const bool go = left >= c;
+                left -= go ? c : 0; p += go ? sh : 0;
             }
-        } else
-        for (int w = 0; w < W; ++w) {
-            const int cnt = pc[w * AG + at];
-            unsigned bits = 0;
-            if (cnt) {
-                const int wi = prefix >> 5, sh = prefix & 31;
-                const u64 two = ((u64)rsel[(wi + 1) * AG + at] << 32) | rsel[wi * AG + at];
-                bits = (unsigned)(two >> sh) & (cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u));
+            it &= ~((1u << p) - 1u);                                   // p <= 31: the within-th set bit exists (k0 < k1)
+        }
+        int slot = k0;                                                 // uncapped: rank = slot
+        if (any_sub) {                                                 // slot of rank k0 = selected ranks below it
+            slot = 0;
+            for (int q = 0; q * 32 < W * 32 && q <= W; ++q) {
+                const unsigned rw = rsel[q * AG + at];
+                const int lo = k0 - q * 32;
+                slot += lo >= 32 ? __popc(rw) : (lo > 0 ? __popc(rw & ((1u << lo) - 1u)) : 0);
             }
-            if (mine(w)) {
-                unsigned it = sbits[w * AG + at], sel = bits;
-                int s = sbase;
-                while (it) {                                   // up to 4 kept bits per trip
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool has = it != 0;
-                        const int b = has ? __ffs(it) - 1 : 0;
-                        it &= it - 1;                          // 0 stays 0
-                        const bool take = has && (sel & 1u);
-                        if (take) row[s] = (short)(w * 32 + b);
-                        s += take ? 1 : 0;
-                        sel >>= 1;
-                    }
+        }
+        int k = k0;
+        while (__any(k < k1)) {
+            if (k < k1) {
+                if (it == 0) { ++ww; it = sbits[ww * AG + at]; }       // next word (more kept bits exist: k < k1 <= n_kept)
+                if (it != 0) {
+                    const int b = __ffs(it) - 1;
+                    it &= it - 1;
+                    const bool take = !any_sub || ((rsel[(k >> 5) * AG + at] >> (k & 31)) & 1u) != 0;
+                    if (take) row[slot] = (short)(ww * 32 + b);
+                    slot += take ? 1 : 0;
+                    ++k;
                 }
             }
-            sbase += __popc(bits);
-            prefix += cnt;
         }
         }
         for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
