@@ -1010,6 +1010,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // The cap is rare (an agent deep inside a fine-celled shape): when no agent of this wave is capped -- the same
     // answer in all WPE splits, they hold the same agents -- ranks are slots and the rank-select bits are skipped.
     const bool any_sub = __any(n_kept > G) != 0;
+    int *sub_base = part_c;                  // [WPE][AG] first slot of each split's rank range, capped agents only (part_c is consumed)
     if (any_sub)
     for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
         FENCE();
@@ -1031,16 +1032,29 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const unsigned nm1 = (unsigned)(__builtin_amdgcn_readlane(n_kept, L) - 1);
             const double step = (double)nm1 / (G - 1);
             unsigned *rl = rsel + (at & ~63) + L;                                  // agent thread of lane L in this wave
-            for (int q = lane; q < G; q += 64) {
-                unsigned r;
-                if (P.cap_int) {
-                    const unsigned x = 2u * (unsigned)q * nm1 + (unsigned)(G - 1);
-                    const unsigned hq = __umulhi(x, P.cap_magic);
-                    r = (((x - hq) >> 1) + hq) >> P.cap_shift;                 // x / (2 (G-1)), Granlund-Montgomery
-                } else {
-                    r = (unsigned)(int)round(q * step);
+            const unsigned perL = (nm1 + 1 + WPE - 1) / WPE;                       // ranks per split in the emission below
+            int below[WPE];                                                        // selected ranks below split s's first rank
+#pragma unroll
+            for (int sp_ = 0; sp_ < WPE; ++sp_) below[sp_] = 0;
+            for (int q0 = 0; q0 < G; q0 += 64) {
+                const int q = q0 + lane;
+                unsigned r = 0xFFFFFFFFu;
+                if (q < G) {
+                    if (P.cap_int) {
+                        const unsigned x = 2u * (unsigned)q * nm1 + (unsigned)(G - 1);
+                        const unsigned hq = __umulhi(x, P.cap_magic);
+                        r = (((x - hq) >> 1) + hq) >> P.cap_shift;                 // x / (2 (G-1)), Granlund-Montgomery
+                    } else {
+                        r = (unsigned)(int)round(q * step);
+                    }
+                    atomicOr(&rl[(r >> 5) * AG], 1u << (r & 31));
                 }
-                atomicOr(&rl[(r >> 5) * AG], 1u << (r & 31));
+#pragma unroll
+                for (int sp_ = 1; sp_ < WPE; ++sp_) below[sp_] += __popcll(__ballot(r < (unsigned)sp_ * perL));
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int sp_ = 1; sp_ < WPE; ++sp_) sub_base[sp_ * AG + (at & ~63) + L] = below[sp_];
             }
         }
     }
@@ -1057,15 +1071,13 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int k0 = sx * per < n_kept ? sx * per : n_kept;
         const int k1 = k0 + per < n_kept ? k0 + per : n_kept;
         // the word holding rank k0 and the number of kept bits before k0 inside it
-        int ww = 0, within = 0;
+        int ww = 0, within = k0;
         {
-            int prefix = 0; bool found = false;
-            for (int w = 0; w < W; ++w) {
-                const int cnt = pc[w * AG + at];
-                const bool here = !found && prefix + cnt > k0;
-                ww = here ? w : ww; within = here ? k0 - prefix : within;
-                found = found || here;
-                prefix += cnt;
+            int prefix = 0;
+            for (int w = 0; w < W; ++w) {                              // ww = number of words whose running count is <= k0
+                prefix += pc[w * AG + at];
+                const bool le = prefix <= k0;
+                ww += le ? 1 : 0; within = le ? k0 - prefix : within;
             }
         }
         unsigned it = k0 < k1 ? sbits[ww * AG + at] : 0u;
@@ -1079,26 +1091,21 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
             it &= ~((1u << p) - 1u);                                   // p <= 31: the within-th set bit exists (k0 < k1)
         }
-        int slot = k0;                                                 // uncapped: rank = slot
-        if (any_sub) {                                                 // slot of rank k0 = selected ranks below it
-            slot = 0;
-            for (int q = 0; q * 32 < W * 32 && q <= W; ++q) {
-                const unsigned rw = rsel[q * AG + at];
-                const int lo = k0 - q * 32;
-                slot += lo >= 32 ? __popc(rw) : (lo > 0 ? __popc(rw & ((1u << lo) - 1u)) : 0);
-            }
-        }
+        // uncapped agent: rank = slot; capped: the rank-select pass counted the selected ranks below each split's range
+        int slot = (n_kept > G && sx > 0) ? sub_base[sx * AG + at] : (n_kept > G ? 0 : k0);
         int k = k0;
+        unsigned rw = (any_sub && k0 < k1) ? rsel[(k0 >> 5) * AG + at] : 0xFFFFFFFFu;      // selection bits of ranks 32 (k >> 5) ...
         while (__any(k < k1)) {
             if (k < k1) {
                 if (it == 0) { ++ww; it = sbits[ww * AG + at]; }       // next word (more kept bits exist: k < k1 <= n_kept)
                 if (it != 0) {
                     const int b = __ffs(it) - 1;
                     it &= it - 1;
-                    const bool take = !any_sub || ((rsel[(k >> 5) * AG + at] >> (k & 31)) & 1u) != 0;
+                    const bool take = ((rw >> (k & 31)) & 1u) != 0;
                     if (take) row[slot] = (short)(ww * 32 + b);
                     slot += take ? 1 : 0;
                     ++k;
+                    if (any_sub && (k & 31) == 0 && k < k1) rw = rsel[(k >> 5) * AG + at];
                 }
             }
         }
