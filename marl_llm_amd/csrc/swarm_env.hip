@@ -85,6 +85,7 @@ struct KP {
     int off_cxyf, off_partc, off_lat, off_cov, off_flag;
     int lattice;               // every env's cells are a lattice subset: row-run path for sensed / occupied bits
     int lat_rw, lat_cw;        // row half-windows (lattice steps) for d_sen and r_avoid/2
+    int lat_nrs, lat_nrc;      // rows a radius can touch: floor(2 (rho_max + margin)) + 1, for d_sen and r_avoid/2
     int lat_n32;               // every env's lattice has <= 32 columns: 32-bit row masks
     double c_near_hi;          // c_near * (1 + 1e-9): pairs in [c_near, c_near_hi) flag the exact occupied-cell path
     const LatEnv *lat;
@@ -741,10 +742,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         };
         for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
             FENCE();
-            const int b0s = (int)floorf(bpf) - P.lat_rw;
-            for (int t = wr; t < 2 * P.lat_rw + 2; t += WS) row_run(b0s + t, L.R, P.c_sen, sbits, false);
-            const int b0c = (int)floorf(bpf) - P.lat_cw;
-            for (int t = wr; t < 2 * P.lat_cw + 2; t += WS) row_run(b0c + t, L.Rc, P.c_occ, cov + el * (P.ngw + 1), true);
+            // rows b with |b - bpf| < rho + margin: the first is ceil(bpf - rho - margin), at most floor(2 (rho + margin)) + 1
+            // of them (lat_nrs / lat_nrc: that count for the largest rho of any env)
+            const int b0s = (int)ceilf(bpf - (L.R + 2.0f * lat_m));
+            for (int t = wr; t < P.lat_nrs; t += WS) row_run(b0s + t, L.R, P.c_sen, sbits, false);
+            const int b0c = (int)ceilf(bpf - (L.Rc + 2.0f * lat_m));
+            for (int t = wr; t < P.lat_nrc; t += WS) row_run(b0c + t, L.Rc, P.c_occ, cov + el * (P.ngw + 1), true);
             // nearest cell (CPP:858-908) from the lattice too: in row b the nearest cell is the set column closest to
             // the agent's column coordinate, on either side of it -- two candidates per row, rows dealt over the splits.
             // best / runner-up are tracked in lattice units; a runner-up within the model's error of the best sends the
@@ -2040,7 +2043,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     }
     k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag; k.hit = h->d_hit;
     k.cells = h->d_cells; k.cells_xy = h->d_cells_xy; k.n_g = h->d_ng; k.c_in = h->d_cin;
-    k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_n32 = 0;
+    k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_nrs = k.lat_nrc = 0; k.lat_n32 = 0;
     k.c_near_hi = k.c_near * (1.0 + 1e-9);
     *out = h;
     return SWARM_OK;
@@ -2131,6 +2134,7 @@ int swarm_set_cells(swarm_env_t *h, int env_begin, int count, const double *cell
         h->kp.lat_n32 = ncmax <= 32 ? 1 : 0;
         h->kp.lat_rw = (int)std::ceil(rmax + 0.02f);
         h->kp.lat_cw = (int)std::ceil(cmax + 0.02f);
+        h->kp.lat_nrs = (int)std::floor(2.0f * (rmax + 0.01f)) + 1; h->kp.lat_nrc = (int)std::floor(2.0f * (cmax + 0.01f)) + 1;
         if (h->kp.lat_rw > 30) h->kp.lattice = 0;           // sensing radius of > 30 cells: not worth a row walk
     }
     for (int k = 0; k < count; ++k) h->cells_set[(size_t)(env_begin + k)] = 1;
@@ -2204,6 +2208,7 @@ int swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_off
     h->kp.lattice = h->shapes_lattice ? 1 : 0;
     h->kp.lat_rw = (int)std::ceil(h->shapes_rmax + 0.02f);
     h->kp.lat_cw = (int)std::ceil(h->shapes_cmax + 0.02f);
+    h->kp.lat_nrs = (int)std::floor(2.0f * (h->shapes_rmax + 0.01f)) + 1; h->kp.lat_nrc = (int)std::floor(2.0f * (h->shapes_cmax + 0.01f)) + 1;
     h->kp.lat_n32 = h->shapes_ncols <= 32 ? 1 : 0;
     if (h->kp.lat_rw > 30) h->kp.lattice = 0;
     h->observed = false;
