@@ -1276,22 +1276,18 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int rep = 0, reps = REPS(7); rep < reps; ++rep) {
             FENCE();
             const int total = rows * HP;
-            const int dr = T / HP, dq = T % HP;
-            int r = tid / HP, q = tid % HP;
-            for (int L = tid; L < total; L += T) {
+            // every pair is (minuend - subtrahend) of the same kind of quantity: half 0 = positions, half 1 =
+            // velocities (the sp array is [px | py | vx | vy], so `half` selects the array pair).  Self block: own
+            // value - 0; neighbour k: neighbour's value - own (zero pair without a neighbour, CPP:79-81); target
+            // block: in shape (own - own), else (cell - own) for the position and (0 - own) for the velocity (CPP:136-137).
+            auto head_pair = [&](int r, int q, int half, bool is_tgt, bool is_nei, int nslot) {
                 const int elr = EPB > 1 ? r / n_a : 0;
                 const int tr = elr * NPAD + (r - elr * n_a);
-                // every pair is (minuend - subtrahend) of the same kind of quantity: half 0 = positions, half 1 =
-                // velocities (the sp array is [px | py | vx | vy], so `half` selects the array pair).  Self block: own
-                // value - 0; neighbour k: neighbour's value - own (zero pair without a neighbour, CPP:79-81); target
-                // block: in shape (own - own), else (cell - own) for the position and (0 - own) for the velocity (CPP:136-137).
-                const int blk = q >> 1, half = q & 1;
                 const double *sa = sp + half * 2 * AG;
                 const double own_a = sa[tr], own_b = sa[AG + tr];
                 double ma = own_a, mb = own_b, sa_ = 0.0, sb_ = 0.0;            // self block
-                const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
                 if (is_nei) {
-                    const int j = snei[tr * kNeiStride + (blk - P.with_self)];
+                    const int j = snei[tr * kNeiStride + nslot];
                     const int tj = elr * NPAD + (j < 0 ? 0 : j);
                     const double na = sa[tj], nb_ = sa[AG + tj];
                     ma = j >= 0 ? na : 0.0; mb = j >= 0 ? nb_ : 0.0;
@@ -1309,8 +1305,24 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 if (P.periodic && is_nei && half == 0) wrap_rel(a, b, P.w_half, P.h_half);      // CPP:79 relative position, wrapped
                 OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
                 out[(size_t)r * PPR + q] = o;
-                q += dq; r += dr;
-                if (q >= HP) { q -= HP; ++r; }
+            };
+            if (T % HP == 0) {
+                // the usual case (HP = 16): a thread keeps its pair index q for all its rows, so the kind of pair it
+                // produces is decided once, outside the loop
+                const int q = tid % HP, blk = q >> 1, half = q & 1;
+                const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
+                const int nslot = blk - P.with_self;
+                for (int r = tid / HP; r < rows; r += T / HP) head_pair(r, q, half, is_tgt, is_nei, nslot);
+            } else {
+                const int dr = T / HP, dq = T % HP;
+                int r = tid / HP, q = tid % HP;
+                for (int L = tid; L < total; L += T) {
+                    const int blk = q >> 1, half = q & 1;
+                    const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
+                    head_pair(r, q, half, is_tgt, is_nei, blk - P.with_self);
+                    q += dq; r += dr;
+                    if (q >= HP) { q -= HP; ++r; }
+                }
             }
         }
         EXIT_AT(11);
