@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -59,16 +60,19 @@ constexpr int kChunks = 7;                                                  // 2
 constexpr int kPre = kChunkFrags * 64 / (64 * kWaves);                      // 16-byte pieces per thread and chunk: 9
 constexpr int kSmemBytes = 2 * kChunkFrags * 64 * 16;                       // 72 KB
 
-template <bool IN_BF16>
-__global__ void __launch_bounds__(64 * kWaves, 2)
+// TPW = row tiles (32 rows each) per wave.  With one tile every MFMA needs its own 1 KB weight-fragment read from LDS (four
+// SIMDs at full MFMA rate would ask for exactly the LDS bandwidth, 128 B/clk); with two tiles each read feeds two MFMAs at
+// the price of ~390 VGPRs, i.e. one wave per SIMD -- measured slower, so TPW = 1 is what runs (see swarm_policy_forward).
+template <bool IN_BF16, int TPW>
+__global__ void __launch_bounds__(64 * kWaves, TPW == 1 ? 2 : 1)
 k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict__ act)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     bf8 *const buf[2] = {reinterpret_cast<bf8 *>(smem_raw), reinterpret_cast<bf8 *>(smem_raw) + kChunkFrags * 64};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const long long row = ((long long)blockIdx.x * kWaves + wave) * 32 + r;
-    const bool wave_on = ((long long)blockIdx.x * kWaves + wave) * 32 < P.rows;     // idle waves still stage and take the barriers
+    const long long row0 = ((long long)blockIdx.x * kWaves + wave) * (32 * TPW) + r;    // this lane's row in tile 0
+    const bool wave_on = row0 - r < P.rows;                                             // idle waves still stage and take the barriers
 
     bf8 pre[kPre];
     auto issue = [&](int c) {                                               // chunk c of the weight stream -> registers
@@ -87,32 +91,40 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
     issue(0);
     // the 12 B fragments of layer 1, straight from the observation row (natural k order); later `pk` holds the packed
     // activations of the previous layer (k-step = 2 * feature tile + s)
-    bf8 pk[kKS];
-    f16v acc[kMT];
+    bf8 pk[TPW][kKS];
+    f16v acc[TPW][kMT];
     if (wave_on) {
-        const size_t xoff = (size_t)(row < P.rows ? row : P.rows - 1) * P.in_dim;
-        const float *x = static_cast<const float *>(obs_) + xoff;
-        const __bf16 *xb = static_cast<const __bf16 *>(obs_) + xoff;
 #pragma unroll
-        for (int ks = 0; ks < kKS; ++ks) {
-            const int k0 = 16 * ks + 8 * h;
-            if constexpr (IN_BF16) {                                        // the fragment as it lies in memory (in_dim % 8 == 0)
-                bf8 z;
+        for (int t = 0; t < TPW; ++t) {
+            const long long row = row0 + 32 * t;
+            const size_t xoff = (size_t)(row < P.rows ? row : P.rows - 1) * P.in_dim;
+            const float *x = static_cast<const float *>(obs_) + xoff;
+            const __bf16 *xb = static_cast<const __bf16 *>(obs_) + xoff;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
-                pk[ks] = k0 < P.in_dim ? *reinterpret_cast<const bf8 *>(xb + k0) : z;
-                continue;
+            for (int ks = 0; ks < kKS; ++ks) {
+                const int k0 = 16 * ks + 8 * h;
+                if constexpr (IN_BF16) {                                    // the fragment as it lies in memory (in_dim % 8 == 0)
+                    bf8 z;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
+                    pk[t][ks] = k0 < P.in_dim ? *reinterpret_cast<const bf8 *>(xb + k0) : z;
+                    continue;
+                }
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                if (k0 < P.in_dim) lo = *reinterpret_cast<const float4 *>(x + k0);          // in_dim is a multiple of 4
+                if (k0 + 4 < P.in_dim) hi = *reinterpret_cast<const float4 *>(x + k0 + 4);
+                pk[t][ks][0] = (__bf16)lo.x; pk[t][ks][1] = (__bf16)lo.y; pk[t][ks][2] = (__bf16)lo.z; pk[t][ks][3] = (__bf16)lo.w;
+                pk[t][ks][4] = (__bf16)hi.x; pk[t][ks][5] = (__bf16)hi.y; pk[t][ks][6] = (__bf16)hi.z; pk[t][ks][7] = (__bf16)hi.w;
             }
-            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-            if (k0 < P.in_dim) lo = *reinterpret_cast<const float4 *>(x + k0);              // in_dim is a multiple of 4
-            if (k0 + 4 < P.in_dim) hi = *reinterpret_cast<const float4 *>(x + k0 + 4);
-            pk[ks][0] = (__bf16)lo.x; pk[ks][1] = (__bf16)lo.y; pk[ks][2] = (__bf16)lo.z; pk[ks][3] = (__bf16)lo.w;
-            pk[ks][4] = (__bf16)hi.x; pk[ks][5] = (__bf16)hi.y; pk[ks][6] = (__bf16)hi.z; pk[ks][7] = (__bf16)hi.w;
         }
 #pragma unroll
         for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[mt][reg] = P.b1[feat_of(mt, reg, h)];
+            for (int reg = 0; reg < 16; ++reg) {
+                const float bv = P.b1[feat_of(mt, reg, h)];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t][mt][reg] = bv;
+            }
     }
     commit(0);
     __syncthreads();
@@ -127,33 +139,44 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
 #pragma unroll
                 for (int ks = 0; ks < kKS; ++ks)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m)
-                        acc[3 * half + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(m * kKS + ks) * 64 + lane], pk[ks], acc[3 * half + m], 0, 0, 0);
+                    for (int m = 0; m < 3; ++m) {
+                        const bf8 a = wl[(m * kKS + ks) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t)
+                            acc[t][3 * half + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pk[t][ks], acc[t][3 * half + m], 0, 0, 0);
+                    }
                 if (half == 1) {                                            // layer complete: leaky ReLU (slope 0.01, networks.py:40-42), pack
 #pragma unroll
-                    for (int kt = 0; kt < kMT; ++kt)
+                    for (int t = 0; t < TPW; ++t) {
 #pragma unroll
-                        for (int s = 0; s < 2; ++s)
+                        for (int kt = 0; kt < kMT; ++kt)
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float v = acc[kt][8 * s + j];
-                                pk[2 * kt + s][j] = (__bf16)fmaxf(v, 0.01f * v);
-                            }
+                            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int mt = 0; mt < kMT; ++mt)
+                                for (int j = 0; j < 8; ++j) {
+                                    const float v = acc[t][kt][8 * s + j];
+                                    pk[t][2 * kt + s][j] = (__bf16)fmaxf(v, 0.01f * v);
+                                }
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) acc[mt][reg] = 0.0f;
+                        for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                            for (int reg = 0; reg < 16; ++reg) acc[t][mt][reg] = 0.0f;
+                    }
                 }
             } else {
                 // output layer: one feature tile; action k is accumulator register k of the lower lane half (row = reg, h = 0)
-                f16v o = acc[0];                                            // zeros
 #pragma unroll
-                for (int ks = 0; ks < kKS; ++ks) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks * 64 + lane], pk[ks], o, 0, 0, 0);
-                if (h == 0 && row < P.rows) {
-                    float *y = act + (size_t)row * P.act_dim;
+                for (int t = 0; t < TPW; ++t) {
+                    f16v o = acc[t][0];                                     // zeros
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < P.act_dim) y[k] = tanhf(o[k]);              // networks.py:43 tanh output
+                    for (int ks = 0; ks < kKS; ++ks) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks * 64 + lane], pk[t][ks], o, 0, 0, 0);
+                    const long long row = row0 + 32 * t;
+                    if (h == 0 && row < P.rows) {
+                        float *y = act + (size_t)row * P.act_dim;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < P.act_dim) y[k] = tanhf(o[k]);          // networks.py:43 tanh output
+                    }
                 }
             }
         }
@@ -284,15 +307,28 @@ static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int6
     if (hipSetDevice(p->device) != hipSuccess) { g_policy_error = "swarm_policy_forward: hipSetDevice failed"; return SWARM_POLICY_ERR_HIP; }
     MlpParams q = p->p;
     q.rows = rows;
-    const long long per_block = (long long)kWaves * 32;
+    // one row tile per wave; the two-tile instantiation (SWARM_POLICY_TPW=2, measurement knob) is slower: 98 vs 87 us on
+    // 262144 bf16 rows, 118 vs 106 us on fp32 rows -- one wave per SIMD costs more than the halved LDS reads give back
+    int tpw = 1;
+    if (const char *ev = std::getenv("SWARM_POLICY_TPW")) tpw = ev[0] == '2' ? 2 : 1;
+    const long long per_block = (long long)kWaves * 32 * tpw;
     const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
     if (!p->smem_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
         p->smem_set = true;
     }
-    if (in_bf16) hipLaunchKernelGGL(k_policy_mlp<true>, dim3(grid), dim3(64 * kWaves), kSmemBytes, static_cast<hipStream_t>(stream), q, obs, act);
-    else hipLaunchKernelGGL(k_policy_mlp<false>, dim3(grid), dim3(64 * kWaves), kSmemBytes, static_cast<hipStream_t>(stream), q, obs, act);
+    const dim3 g(grid), b(64 * kWaves);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (tpw == 2) {
+        if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 2>), g, b, kSmemBytes, st, q, obs, act);
+        else hipLaunchKernelGGL((k_policy_mlp<false, 2>), g, b, kSmemBytes, st, q, obs, act);
+    } else {
+        if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 1>), g, b, kSmemBytes, st, q, obs, act);
+        else hipLaunchKernelGGL((k_policy_mlp<false, 1>), g, b, kSmemBytes, st, q, obs, act);
+    }
     const hipError_t e = hipGetLastError();
     (void)hipSetDevice(prev);
     if (e != hipSuccess) { g_policy_error = std::string("swarm_policy_forward: ") + hipGetErrorString(e); return SWARM_POLICY_ERR_HIP; }
