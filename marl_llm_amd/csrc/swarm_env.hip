@@ -1333,9 +1333,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const int Gp = P.g_max;
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
             const int nfull = Gp >> 6, tail = Gp & 63;
-#ifdef EXP_UNROLL
-#pragma unroll EXP_UNROLL
-#endif
             for (int r = wv; r < rows; r += nwv) {
                 const int elr = EPB > 1 ? r / n_a : 0;
                 const int tr = elr * NPAD + (r - elr * n_a);
