@@ -318,15 +318,16 @@ def test_threshold_adversarial_inputs(oracle, shapes, n_a, n_env, force):
 
 
 def test_forced_exact_paths_equal_fast_paths(shapes):
-    """Whole-batch consistency: fast (fp32 pre-filter) and forced-exact runs give identical outputs over
-    several free-running steps at a BASELINE-sized agent count."""
+    """Whole-batch consistency: fast and forced-exact runs, lattice walk and generic scan (debug_flags 0..3) give
+    identical outputs over several free-running steps at a BASELINE-sized agent count (tools/stress_consistency.py
+    runs the same comparison at millions of agent-steps)."""
     from marl_llm_amd.shapes import r_avoid_for
     from marl_llm_amd.synth import synthetic_batch
     n_a, n_env = 64, 512
     ra = r_avoid_for(n_a, shapes)
     sy = synthetic_batch(n_env, n_a, shapes, seed=11, assembled_fraction=0.6)
     outs = []
-    for force in (0, 1):
+    for force in (0, 1, 2, 3):
         sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra, debug_flags=force)
         sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"]); sb.set_state(sy["p"], sy["dp"]); sb.observe()
         act = torch.zeros((n_env, n_a, 2), device=sb.device)
@@ -338,8 +339,9 @@ def test_forced_exact_paths_equal_fast_paths(shapes):
         idx = sb.indices()
         outs.append((obs.clone(), torch.stack(rews), p, dp, idx["sensed_index"], idx["occupied_index"], idx["in_flags"]))
         sb.close()
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
     assert outs[0][1].sum().item() > 0          # some agents do earn the reward in this workload
 
 
