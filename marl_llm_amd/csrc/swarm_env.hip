@@ -1096,22 +1096,28 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         // uncapped agent: rank = slot; capped: the rank-select pass counted the selected ranks below each split's range
         int slot = (n_kept > G && sx > 0) ? sub_base[sx * AG + at] : (n_kept > G ? 0 : k0);
-        int k = k0;
-        unsigned rw = (any_sub && k0 < k1) ? rsel[(k0 >> 5) * AG + at] : 0xFFFFFFFFu;      // selection bits of ranks 32 (k >> 5) ...
-        while (__any(k < k1)) {
-            if (k < k1) {
-                if (it == 0) { ++ww; it = sbits[ww * AG + at]; }       // next word (more kept bits exist: k < k1 <= n_kept)
-                if (it != 0) {
-                    const int b = __ffs(it) - 1;
-                    it &= it - 1;
-                    const bool take = ((rw >> (k & 31)) & 1u) != 0;
-                    if (take) row[slot] = (short)(ww * 32 + b);
-                    slot += take ? 1 : 0;
-                    ++k;
-                    if (any_sub && (k & 31) == 0 && k < k1) rw = rsel[(k >> 5) * AG + at];
+        // two instantiations of the walk: without a capped agent in the wave every kept bit is taken and no selection
+        // word is carried
+        auto walk_range = [&](auto capped) {
+            constexpr bool CAP = decltype(capped)::value;
+            int k = k0;
+            unsigned rw = (CAP && k0 < k1) ? rsel[(k0 >> 5) * AG + at] : 0xFFFFFFFFu;      // selection bits of ranks 32 (k >> 5) ...
+            while (__any(k < k1)) {
+                if (k < k1) {
+                    if (it == 0) { ++ww; it = sbits[ww * AG + at]; }   // next word (more kept bits exist: k < k1 <= n_kept)
+                    if (it != 0) {
+                        const int b = __ffs(it) - 1;
+                        it &= it - 1;
+                        const bool take = !CAP || ((rw >> (k & 31)) & 1u) != 0;
+                        if (take) row[slot] = (short)(ww * 32 + b);
+                        slot += take ? 1 : 0;
+                        ++k;
+                        if (CAP && (k & 31) == 0 && k < k1) rw = rsel[(k >> 5) * AG + at];
+                    }
                 }
             }
-        }
+        };
+        if (any_sub) walk_range(std::true_type{}); else walk_range(std::false_type{});
         }
         for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
     }
