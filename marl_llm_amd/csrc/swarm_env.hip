@@ -1181,20 +1181,23 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         u64 um = __ballot(unsure);
         if (um != 0) {
             const double inv_dsen = 1.0 / P.d_sen;
-            if constexpr (NW == 1) {
+            {
                 // exact (CPP:529-549), wave-cooperative: for each unsure agent (rarely more than one per wave) the 64 lanes
                 // evaluate one list slot each in fp64 -- psi needs a sqrt and a 12-term cosine -- and park the three
                 // products in LDS; the sums then run over them sequentially in slot order, which is the reference's
                 // order of additions.  (A lane looping alone over its list made this workgroup a straggler.)
-                double *scr = reinterpret_cast<double *>(smem + P.off_cmask);       // [3][64]; rsum (read above) is dead
+                // scratch [3][64] doubles per wave: over the (dead) rsum for one wave per split, behind it when the other
+                // waves of this split may still be reading theirs
+                double *scr = reinterpret_cast<double *>(smem + P.off_cmask + (NW > 1 ? WPE * 3 * AG * 4 + aw * 1536 : 0));
                 while (um != 0) {
                     const int L = __ffsll((unsigned long long)um) - 1;               // agent thread, wave-uniform
                     um &= um - 1;
                     const int nL = __builtin_amdgcn_readlane(n_sel, L);
                     const int eL = blockIdx.x * EPB + (NPAD < 64 ? L / NPAD : 0);
                     const double2 *gcl = P.cells_xy + (size_t)eL * P.ng_max;
-                    const double pxl = sp[L], pyl = sp[AG + L];
-                    const short *rowl = sidx + (size_t)L * P.g_stride;
+                    const int La = (at & ~63) + L;                                  // agent thread of lane L in this wave
+                    const double pxl = sp[La], pyl = sp[AG + La];
+                    const short *rowl = sidx + (size_t)La * P.g_stride;
                     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
                     for (int base = 0; base < nL; base += 64) {
                         const int q = base + lane;
@@ -1223,20 +1226,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const bool res = sqrt(v0 * v0 + v1 * v1) < 0.05;
                     if (lane == L) uniform = res;
                 }
-            } else if (unsure) {      // exact: fp64, slot order (CPP:529-549)
-                const short *row = sidx + (size_t)at * P.g_stride;
-                double num0 = 0.0, num1 = 0.0, den = 0.0;
-#pragma unroll 4
-                for (int q = 0; q < n_sel; ++q) {
-                    const double2 g = cell64(row[q]);
-                    const double x = g.x - px, y = g.y - py;
-                    const double z = sqrt(x * x + y * y);
-                    const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
-                    num0 += psi * x; num1 += psi * y; den += psi;
-                }
-                if (den == 0) den = 1E-8;
-                const double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;
-                uniform = sqrt(v0 * v0 + v1 * v1) < 0.05;
             }
         }
         if (act) {
@@ -1827,7 +1816,7 @@ void layout_t(KP &k)
     k.off_cxy = 0;                             // fp64 cells are no longer staged in LDS
     k.off_sp = take((size_t)4 * AG * 8);
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
-    k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
+    k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4 + (NW > 1 ? NW * 1536 : 0)), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
     k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * (NW == 1 ? 4 : 3) * NW * AG * 8));  // sidx | pm
     k.off_partc = take((size_t)WPE * AG * 4);
