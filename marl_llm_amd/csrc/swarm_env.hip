@@ -93,7 +93,7 @@ struct KP {
     double bx0, by1, bx2, by3, w_half, h_half;
     double *p, *dp;
     int *nei, *near_cell, *in_flag;
-    unsigned long long *hit;   // [E][N] (N <= 64): agents overlapping agent i in the CURRENT state (contact pairs of the next step)
+    unsigned long long *hit;   // [E][N][NW]: agents overlapping agent i in the CURRENT state (contact pairs of the next step)
     const double *cells;       // [E][2][ng_max] (the ABI's layout)
     const double2 *cells_xy;   // [E][ng_max] (x, y) interleaved copy: one 16-byte gather per cell
     const int *n_g;
@@ -316,9 +316,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     int pj[kTopoMax]; int ncell = 0, inf = 0;
 #pragma unroll
     for (int k = 0; k < kTopoMax; ++k) pj[k] = -1;
-    u64 hit0 = 0;
+    u64 hit0[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) hit0[w] = 0;
     if (sx == 0 && act) {
-        if (DO_STEP && NW == 1) hit0 = P.hit[(size_t)e * n_a + i];
+        if (DO_STEP) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) hit0[w] = P.hit[((size_t)e * n_a + i) * NW + w];
+        }
         px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
         vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
         if (DO_STEP) {
@@ -432,25 +437,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 // lanes >= n_a hold NaN positions and never compare true.
                 constexpr int KN = NPAD < 64 ? NPAD : 64;
                 const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
+                // which agents k overlap agent i (centre distance < 2 size_a)?  The previous observation pass evaluated exactly
+                // this test on exactly these positions (its post-integration state is this step's pre-integration state)
+                // and left the masks in HBM.
                 u64 hit[NW];
-                if constexpr (NW == 1) {
-                    // the previous observation pass evaluated exactly this test on exactly these positions (its
-                    // post-integration state is this step's pre-integration state) and left the mask in HBM
-                    hit[0] = hit0;
-                } else {
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        u64 h = 0;
-#pragma unroll 8
-                        for (int kk = 0; kk < KN; ++kk) {
-                            const double dx = spx[w * 64 + kk] - px, dy = spy[w * 64 + kk] - py;
-                            const double d2 = dx * dx + dy * dy;
-                            if (d2 < P.c_ball) h |= 1ull << kk;
-                        }
-                        hit[w] = h;
-                    }
-                    if (i < 64 * NW) hit[i >> 6] &= ~(1ull << (i & 63));       // k != i
-                }
+                for (int w = 0; w < NW; ++w) hit[w] = hit0[w];
                 // pass B: the colliding pairs in ascending k (the reference's summation order, CPP:799-807)
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
@@ -548,7 +540,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     const double d2u = rx * rx + ry * ry;
                     a_nb[w] = shl1_or_mask(a_nb[w], __ballot(d2u < P.c_near));
                     a_hi = shl1_or_mask(a_hi, __ballot(d2u < P.c_near_hi));
-                    if constexpr (NW == 1) a_ht[w] = shl1_or_mask(a_ht[w], __ballot(d2u < P.c_ball));   // contact pairs of the NEXT step (ENV:442-457)
+                    a_ht[w] = shl1_or_mask(a_ht[w], __ballot(d2u < P.c_ball));                        // contact pairs of the NEXT step (ENV:442-457)
                     double d2 = d2u;
                     if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
                     a_cd[w] = shl1_or_mask(a_cd[w], __ballot(d2 < P.c_sen));
@@ -585,6 +577,23 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 #pragma unroll
                 for (int q = 0; q < WPE; ++q) hh |= pm[((q * PMK + 3) * NW) * AG + at];
                 P.hit[(size_t)e * n_a + i] = hh & ~(1ull << i);               // k != i
+            }
+        } else {
+            // N > 64: the contact masks take a second trip through the first mask slot (a fourth slot per 64-agent group
+            // would cost the larger workgroups their second resident workgroup)
+            __syncthreads();                                              // everyone has read the first round
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pm[((sx * PMK + 0) * NW + w) * AG + at] = place(a_ht[w]);
+            __syncthreads();
+            if (sx == 0 && act) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    u64 hh = 0;
+#pragma unroll
+                    for (int q = 0; q < WPE; ++q) hh |= pm[((q * PMK + 0) * NW + w) * AG + at];
+                    if (w == (i >> 6)) hh &= ~(1ull << (i & 63));         // k != i
+                    P.hit[((size_t)e * n_a + i) * NW + w] = hh;
+                }
             }
         }
     }
@@ -2030,12 +2039,12 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     alloc((void **)&h->d_ng, E * 4);
     alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
-    alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_hit, E * N * 8);
+    alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_hit, E * N * 8 * (size_t)std::max(1, h->npad / 64));
     if (a == hipSuccess) a = hipMemset(h->d_ng, 0, E * 4);
     if (a == hipSuccess) a = hipMemset(h->d_nei, 0xFF, E * N * (size_t)k.topo * 4);
     if (a == hipSuccess) a = hipMemset(h->d_near, 0, E * N * 4);
     if (a == hipSuccess) a = hipMemset(h->d_inflag, 0, E * N * 4);
-    if (a == hipSuccess) a = hipMemset(h->d_hit, 0, E * N * 8);
+    if (a == hipSuccess) a = hipMemset(h->d_hit, 0, E * N * 8 * (size_t)std::max(1, h->npad / 64));
     if (a == hipSuccess) a = hipMemset(h->d_cells, 0, E * 2 * (size_t)k.ng_max * 8);
     if (a == hipSuccess) a = hipMemset(h->d_cells_xy, 0, E * (size_t)k.ng_max * 16);
     if (a == hipSuccess) a = hipEventCreate(&h->ev0);
