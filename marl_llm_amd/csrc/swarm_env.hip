@@ -184,7 +184,7 @@ template <int NPAD> struct Geo {
     static constexpr int AG = NPAD < 64 ? 64 : NPAD;
     static constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
     static constexpr int NW = AG / 64;
-    static constexpr int WPE = NPAD <= 64 ? 4 : 2;
+    static constexpr int WPE = NPAD <= 128 ? 4 : 2;
     static constexpr int T = AG * WPE;
 #ifndef SWARM_WPS
 #define SWARM_WPS 6
