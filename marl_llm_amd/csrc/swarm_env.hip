@@ -176,10 +176,11 @@ __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
 #endif
 
 // Workgroup geometry.  AG "agent threads" hold the agents of the workgroup's environment(s) (lane = agent);
-// the workgroup has WPE copies ("splits") of them.  Split 0 owns the per-agent sequential work (forces,
-// integration, neighbour search); the target-cell words of the scan / filter / list phases are dealt out
-// over all splits, split 0 getting fewer.  One environment's LDS footprint is thereby shared by WPE times
-// more wavefronts, which is what buys the occupancy that hides the LDS / fp64 latencies.
+// the workgroup has WPE copies ("splits") of them: 4 up to 128 agents, 2 at 256 (four would need more LDS for the
+// partial pair masks than a CU has).  Splits "A" and "B" own the per-agent sequential work (forces / integration /
+// reward decision; prior / ordered neighbour insertion); rows, words, slots and rank ranges of the other phases are
+// dealt over all splits.  One environment's LDS footprint is thereby shared by WPE times more wavefronts, which is
+// what buys the occupancy that hides the LDS / fp64 latencies.
 template <int NPAD> struct Geo {
     static constexpr int AG = NPAD < 64 ? 64 : NPAD;
     static constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
