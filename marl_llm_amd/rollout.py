@@ -8,6 +8,7 @@ ring buffer (train_assembly.py:91-111, maddpg.py:72-87, agents.py:69-96, buffer_
                      module (the learner trains this one).
 * `FusedPolicy`   -- the same forward as one hand-written bf16-MFMA kernel (csrc/policy_mlp.hip) for the rollout.
 * `DeviceReplay`  -- the ring buffer of buffer_agent.py:13-128 with one row per (env, agent) transition, as device tensors.
+* `ChainedReplay` -- the same transitions stored as a ring of env steps that share observation rows (half the copy per push).
 * `rollout`       -- obs -> policy -> exploration noise (agents.py:82-96 continuous branch) -> env.step_tensor -> push.
 
 PyTorch is plumbing here (device memory, GEMMs); the environment step is the HIP library.
@@ -126,6 +127,51 @@ class DeviceReplay:
     def sample(self, batch, generator=None):
         idx = torch.randint(0, self.filled_i, (batch,), device=self.obs.device, generator=generator)
         return self.obs[idx], self.act[idx], self.rew[idx], self.next_obs[idx], self.done[idx], self.act_prior[idx]
+
+
+class ChainedReplay:
+    """Replay of whole env steps in which consecutive transitions SHARE their observation rows: a ring of S = K + 1 step
+    slots; transition j is (obs slot j, act/rew/done/prior of slot j, next_obs = obs slot j + 1).  A push therefore copies
+    one observation block instead of two (the observations are ~97 % of a transition's bytes).  The K most recent steps
+    are valid; the slot after the newest holds that step's next_obs and is excluded from sampling.  Same transitions as
+    DeviceReplay / the reference's buffer (buffer_agent.py:67-128), different storage.  Call `break_chain()` when the
+    next pushed obs is NOT the previous next_obs (after an env reset)."""
+
+    def __init__(self, n_steps, rows_per_step, obs_dim, act_dim, device, obs_dtype=torch.float32):
+        self.K, self.S, self.n = int(n_steps), int(n_steps) + 1, int(rows_per_step)
+        z = lambda d, dt=torch.float32: torch.zeros((self.S, self.n, d), dtype=dt, device=device)
+        self.obs = z(obs_dim, obs_dtype)
+        self.act, self.act_prior = z(act_dim), z(act_dim)
+        self.rew, self.done = z(1), z(1)
+        self.cur, self.count, self._chained = 0, 0, False
+
+    def __len__(self):
+        return self.count * self.n
+
+    def break_chain(self):
+        self._chained = False
+
+    def push(self, obs, act, rew, next_obs, done, act_prior=None):
+        n = self.n
+        if obs.shape[0] * obs.shape[1] != n:
+            raise ValueError("ChainedReplay takes whole env steps of %d rows" % n)
+        c, nx = self.cur, (self.cur + 1) % self.S
+        if not self._chained:
+            self.obs[c] = obs.reshape(n, -1)
+        self.obs[nx] = next_obs.reshape(n, -1)
+        self.act[c] = act.reshape(n, -1)
+        self.rew[c] = rew.reshape(n, 1); self.done[c] = done.reshape(n, 1).to(self.done.dtype)
+        if act_prior is not None:
+            self.act_prior[c] = act_prior.reshape(n, -1).to(self.act_prior.dtype)
+        self.cur, self.count, self._chained = nx, min(self.count + 1, self.K), True
+
+    def sample(self, batch, generator=None):
+        dev = self.obs.device
+        back = torch.randint(0, self.count, (batch,), device=dev, generator=generator)
+        j = (self.cur - 1 - back) % self.S
+        r = torch.randint(0, self.n, (batch,), device=dev, generator=generator)
+        jn = (j + 1) % self.S
+        return self.obs[j, r], self.act[j, r], self.rew[j, r], self.obs[jn, r], self.done[j, r], self.act_prior[j, r]
 
 
 @torch.no_grad()

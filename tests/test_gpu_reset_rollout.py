@@ -129,6 +129,41 @@ def test_device_rollout_and_replay(shapes):
     sb.close()
 
 
+def test_chained_replay_holds_the_same_transitions(shapes):
+    """ChainedReplay (one observation block per step) against DeviceReplay (two) on the same rollout: identical
+    transitions, also after the ring wrapped; sampled (obs, next_obs) pairs are consecutive steps of the same row."""
+    from marl_llm_amd.batched import SwarmBatch
+    from marl_llm_amd.rollout import ChainedReplay, DeviceReplay, PolicyMLP, rollout
+    from marl_llm_amd.shapes import r_avoid_for
+    E, N, K = 16, 32, 4
+    n = E * N
+    ng_max = max(np.asarray(g).shape[0] for g in shapes["grid_coords"])
+    sb = SwarmBatch(n_env=E, n_agents=N, n_cells_max=ng_max, r_avoid=r_avoid_for(N, shapes)); sb.set_shapes(shapes)
+    obs = sb.reset(seed=3)
+    torch.manual_seed(0)
+    policy = PolicyMLP(obs_dim=sb.obs_dim).to(sb.device)
+    flat, chain = DeviceReplay(K * n, sb.obs_dim, 2, sb.device), ChainedReplay(K, n, sb.obs_dim, 2, sb.device)
+
+    class Both:
+        def push(self, *a):
+            flat.push(*a); chain.push(*a)
+    obs, _ = rollout(sb, policy, steps=7, obs=obs, replay=Both(), noise_scale=0.1)       # 7 > K: both rings wrapped
+    assert len(chain) == K * n == len(flat)
+    # flat buffer: rows [curr_i, ...) oldest first; chain: the K steps before slot `cur`
+    order = [(flat.curr_i // n + k) % K for k in range(K)]                              # flat block index of step (newest - K + 1 + k)
+    for k, fb in enumerate(order):
+        j = (chain.cur - K + k) % chain.S
+        sl = slice(fb * n, (fb + 1) * n)
+        assert torch.equal(chain.obs[j], flat.obs[sl]) and torch.equal(chain.obs[(j + 1) % chain.S], flat.next_obs[sl])
+        assert torch.equal(chain.act[j], flat.act[sl]) and torch.equal(chain.rew[j], flat.rew[sl])
+        assert torch.equal(chain.act_prior[j], flat.act_prior[sl])
+    assert torch.equal(chain.obs[chain.cur], obs.reshape(n, -1))                          # the newest next_obs
+    g = torch.Generator(device=sb.device).manual_seed(1)
+    o, a, r, no, d, pr = chain.sample(256, generator=g)
+    assert o.shape == (256, sb.obs_dim) and no.shape == o.shape and a.shape == (256, 2)
+    sb.close()
+
+
 @pytest.mark.parametrize("n_a,n_env", [(8, 5), (30, 6), (64, 8), (200, 3), (256, 2)])
 def test_eval_metrics_match_wrapper_restatement(shapes, n_a, n_env):
     """coverage / min-distance uniformity / Voronoi uniformity (assembly_wrapper.py:48-128) from the kernel equal the

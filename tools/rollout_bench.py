@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from marl_llm_amd.batched import SwarmBatch
-from marl_llm_amd.rollout import DeviceReplay, FusedPolicy, PolicyMLP, rollout
+from marl_llm_amd.rollout import ChainedReplay, DeviceReplay, FusedPolicy, PolicyMLP, rollout
 from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
 
 
@@ -97,6 +97,9 @@ def main():
     print(f"  bf16 rows: env step only                {t_e16 * 1e3:8.3f} ms   {n / t_e16 / 1e6:9.1f} M")
     print(f"  bf16 rows: env + fused policy + noise   {t_f16 * 1e3:8.3f} ms   {n / t_f16 / 1e6:9.1f} M")
     print(f"  bf16 rows: + replay push                {t_f16r * 1e3:8.3f} ms   {n / t_f16r / 1e6:9.1f} M")
+    chain16 = ChainedReplay(8, E * n_a, sb.obs_dim, 2, sb.device, obs_dtype=torch.bfloat16)
+    t_f16c = timed(lambda k: with_fused(k, rep=chain16))
+    print(f"  bf16 rows: + chained replay push        {t_f16c * 1e3:8.3f} ms   {n / t_f16c / 1e6:9.1f} M")
     sb.close()
 
 
