@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: where does one env-step kernel spend its cycles?  Builds/loads the -DSWARM_STAMPS library
 (in-kernel clock64 stamps at phase boundaries, wave 0 of every workgroup) and prints the share of each phase.
-Read SHARES, not absolute time: the stamps fence the scheduler (see cdna_hip_programming.md section 7)."""
+Read SHARES, not absolute time: the stamps fence the scheduler (see cdna_hip_programming.md section 7).  The stamped wave's
+role rotates with the workgroup index, so the shares are an average over the four roles; tools/ablate.py --cumulative is
+the better instrument for throughput."""
 import ctypes
 import os
 import sys
@@ -42,7 +44,6 @@ def main():
            out.ctypes.data_as(ctypes.c_void_p), grid_max)
     assert g > 0, g
     t = out[:g].astype(np.float64)
-    fine = t[:, 8:14]
     t = t[:, :8]
     d = np.diff(t, axis=1)
     tot = t[:, 7] - t[:, 0]
@@ -50,11 +51,6 @@ def main():
           f"(min {tot.min():.0f}, max {tot.max():.0f}); kernel span {(t[:, 7].max() - t[:, 0].min()):.0f} cycles")
     for k, name in enumerate(PHASES):
         print(f"  {name:26s} {d[:, k].mean():10.0f} cycles  {100 * d[:, k].mean() / tot.mean():5.1f} %")
-    t1 = t[:, 1]
-    names = ["contact loop done", "walls done", "prior done", "integration done", "barrier B passed", "neighbour loops done"]
-    print("  split-0 fine stamps (cycles since 'load' end):")
-    for k, nm in enumerate(names):
-        print(f"    {nm:24s} {(fine[:, k] - t1).mean():10.0f}")
 
 
 if __name__ == "__main__":
