@@ -193,7 +193,7 @@ def main():
                        "parallelism": f"env-sharded x{world}, no collective on the step path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload.split(" (")[0] + ", assembled state" if args.state == "assembled" else "-"),
-                         "kernel": "k_env<64,float,true>", "kernel_us": launch_s * 1e6,
+                         "kernel": "k_env<%d,float,true>" % max(8, 1 << (n_a - 1).bit_length()), "kernel_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if cpu is not None:
