@@ -176,8 +176,7 @@ __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
 #endif
 
 // Workgroup geometry.  AG "agent threads" hold the agents of the workgroup's environment(s) (lane = agent);
-// the workgroup has WPE copies ("splits") of them: 4 up to 128 agents, 2 at 256 (four would need more LDS for the
-// partial pair masks than a CU has).  Splits "A" and "B" own the per-agent sequential work (forces / integration /
+// the workgroup has WPE = 4 copies ("splits") of them (256 agents: 1024 threads).  Splits "A" and "B" own the per-agent sequential work (forces / integration /
 // reward decision; prior / ordered neighbour insertion); rows, words, slots and rank ranges of the other phases are
 // dealt over all splits.  One environment's LDS footprint is thereby shared by WPE times more wavefronts, which is
 // what buys the occupancy that hides the LDS / fp64 latencies.
@@ -185,7 +184,7 @@ template <int NPAD> struct Geo {
     static constexpr int AG = NPAD < 64 ? 64 : NPAD;
     static constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
     static constexpr int NW = AG / 64;
-    static constexpr int WPE = NPAD <= 128 ? 4 : 2;
+    static constexpr int WPE = 4;
     static constexpr int T = AG * WPE;
 #ifndef SWARM_WPS
 #define SWARM_WPS 6
@@ -361,6 +360,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
+    if constexpr (NW > 1) {                       // pair-mask accumulators (OR-ed into with LDS atomics)
+        for (int k = sx; k < 4 * NW; k += WPE) pm[k * AG + at] = 0;
+    }
     double warm = 0.0;
     if (use_lat) {
         // lattice mode gathers the fp64 cells from global memory (nearest-cell merge, reward weights, observation
@@ -521,7 +523,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     {
         constexpr int JQ = JN / WPE;                  // agents j per split and 64-agent group
         static_assert(JQ * WPE == JN && JQ <= 32, "pair pass: JN must split evenly into <= 32 agents per split");
-        constexpr int PMK = NW == 1 ? 4 : 3;          // partial masks per split: nearby, candidates, close candidates, (N <= 64) contacts
+        constexpr int PMK = 4;                        // masks per agent: nearby, candidates, close candidates, contacts
         // One compare + one add-with-carry per test: the compare's lane mask is the carry-in of acc = 2 acc + carry, so
         // after the JQ agents of this split bit (JQ-1-q) of acc is the answer for agent q; reversed and shifted into
         // place (agent j = sx*JQ + q) at the end.
@@ -552,47 +554,52 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         if (use_lat && exc) atomicOr(&sflag[at], 1);   // resolve the occupied-cell filter of this agent exactly
         auto place = [&](unsigned acc) -> u64 { return (u64)(__brev(acc) >> (32 - JQ)) << (sx * JQ); };
+        if constexpr (NW == 1) {
+            // N <= 64: every split stores its partial masks, the readers OR the WPE copies
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
-            const u64 nbm = place(a_nb[w]);
-            pm[((sx * PMK + 0) * NW + w) * AG + at] = NPAD < 64 ? (nbm << (el * NPAD)) : nbm;
-            pm[((sx * PMK + 1) * NW + w) * AG + at] = place(a_cd[w]);
-            pm[((sx * PMK + 2) * NW + w) * AG + at] = place(a_c1[w]);
-            if constexpr (NW == 1) pm[((sx * PMK + 3) * NW + w) * AG + at] = place(a_ht[w]);
-        }
-        __syncthreads();
+            for (int w = 0; w < NW; ++w) {
+                // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
+                const u64 nbm = place(a_nb[w]);
+                pm[((sx * PMK + 0) * NW + w) * AG + at] = NPAD < 64 ? (nbm << (el * NPAD)) : nbm;
+                pm[((sx * PMK + 1) * NW + w) * AG + at] = place(a_cd[w]);
+                pm[((sx * PMK + 2) * NW + w) * AG + at] = place(a_c1[w]);
+                pm[((sx * PMK + 3) * NW + w) * AG + at] = place(a_ht[w]);
+            }
+            __syncthreads();
+            nearbyN[0] = 0; candN[0] = 0; cand1N[0] = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            nearbyN[w] = 0; candN[w] = 0; cand1N[w] = 0;
-#pragma unroll
-            for (int q = 0; q < WPE; ++q) nearbyN[w] |= pm[((q * PMK + 0) * NW + w) * AG + at];
+            for (int q = 0; q < WPE; ++q) nearbyN[0] |= pm[(q * PMK + 0) * AG + at];
             if (sx == SB) {
 #pragma unroll
-                for (int q = 0; q < WPE; ++q) { candN[w] |= pm[((q * PMK + 1) * NW + w) * AG + at]; cand1N[w] |= pm[((q * PMK + 2) * NW + w) * AG + at]; }
+                for (int q = 0; q < WPE; ++q) { candN[0] |= pm[(q * PMK + 1) * AG + at]; cand1N[0] |= pm[(q * PMK + 2) * AG + at]; }
             }
-        }
-        if constexpr (NW == 1) {
             if (sx == 0 && act) {
                 u64 hh = 0;
 #pragma unroll
-                for (int q = 0; q < WPE; ++q) hh |= pm[((q * PMK + 3) * NW) * AG + at];
+                for (int q = 0; q < WPE; ++q) hh |= pm[(q * PMK + 3) * AG + at];
                 P.hit[(size_t)e * n_a + i] = hh & ~(1ull << i);               // k != i
             }
         } else {
-            // N > 64: the contact masks take a second trip through the first mask slot (a fourth slot per 64-agent group
-            // would cost the larger workgroups their second resident workgroup)
-            __syncthreads();                                              // everyone has read the first round
+            // N > 64: per-split copies of 4 masks x NW groups would not fit beside the rest; the splits OR their parts
+            // into ONE set of accumulators (zeroed in the prologue) with LDS atomics
 #pragma unroll
-            for (int w = 0; w < NW; ++w) pm[((sx * PMK + 0) * NW + w) * AG + at] = place(a_ht[w]);
+            for (int w = 0; w < NW; ++w) {
+                atomicOr(&pm[(0 * NW + w) * AG + at], place(a_nb[w]));
+                atomicOr(&pm[(1 * NW + w) * AG + at], place(a_cd[w]));
+                atomicOr(&pm[(2 * NW + w) * AG + at], place(a_c1[w]));
+                atomicOr(&pm[(3 * NW + w) * AG + at], place(a_ht[w]));
+            }
             __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                nearbyN[w] = pm[(0 * NW + w) * AG + at]; candN[w] = 0; cand1N[w] = 0;
+                if (sx == SB) { candN[w] = pm[(1 * NW + w) * AG + at]; cand1N[w] = pm[(2 * NW + w) * AG + at]; }
+            }
             if (sx == 0 && act) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    u64 hh = 0;
-#pragma unroll
-                    for (int q = 0; q < WPE; ++q) hh |= pm[((q * PMK + 0) * NW + w) * AG + at];
-                    if (w == (i >> 6)) hh &= ~(1ull << (i & 63));         // k != i
+                    u64 hh = pm[(3 * NW + w) * AG + at];
+                    if (w == (i >> 6)) hh &= ~(1ull << (i & 63));             // k != i
                     P.hit[((size_t)e * n_a + i) * NW + w] = hh;
                 }
             }
@@ -1828,7 +1835,7 @@ void layout_t(KP &k)
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4 + (NW > 1 ? NW * 1536 : 0)), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)WPE * (NW == 1 ? 4 : 3) * NW * AG * 8));  // sidx | pm
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)(NW == 1 ? WPE : 1) * 4 * NW * AG * 8));  // sidx | pm (per-split copies for N <= 64, one accumulator set above)
     k.off_partc = take((size_t)WPE * AG * 4);
     k.off_lat = take((size_t)EPB * 64 * (8 + 2));
     k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
