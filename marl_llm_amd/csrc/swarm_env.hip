@@ -176,10 +176,10 @@ __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
 #endif
 
 // Workgroup geometry.  AG "agent threads" hold the agents of the workgroup's environment(s) (lane = agent);
-// the workgroup has WPE = 4 copies ("splits") of them (256 agents: 1024 threads).  Splits "A" and "B" own the per-agent sequential work (forces / integration /
-// reward decision; prior / ordered neighbour insertion); rows, words, slots and rank ranges of the other phases are
-// dealt over all splits.  One environment's LDS footprint is thereby shared by WPE times more wavefronts, which is
-// what buys the occupancy that hides the LDS / fp64 latencies.
+// the workgroup has WPE = 4 copies ("splits") of them (256 agents: 1024 threads).  Splits "A" and "B" own the
+// per-agent sequential work (forces / integration / reward decision; prior / ordered neighbour insertion); rows,
+// words, slots and rank ranges of the other phases are dealt over all splits.  One environment's LDS footprint is
+// thereby shared by four times more wavefronts, which is what buys the occupancy that hides the LDS / fp64 latencies.
 template <int NPAD> struct Geo {
     static constexpr int AG = NPAD < 64 ? 64 : NPAD;
     static constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
