@@ -71,7 +71,7 @@ struct KP {
     int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear, off_pc;
     int smem_lat, smem_lat_export, smem_generic;   // dynamic LDS bytes by launch kind
     double c_sen, c_near, c_occ, c_avoid, c_ball;     // squared-distance cut-offs
-    double c_close;            // (1.9 r_avoid)^2 capped at c_sen: pre-selection radius of the neighbour insertion (any value is exact)
+    double c_close, c_close2;  // (1.9 r_avoid)^2 and (3 r_avoid)^2 capped at c_sen: pre-selection radii of the neighbour insertion (any values are exact; the second is used for N > 128)
     // fp32 pre-filter bands: d2_32 < *_lo  =>  exact test true;  d2_32 >= *_hi  =>  exact test false
     float csen_lo, csen_hi, cocc_lo, cocc_hi;
     float coord_lim;           // |coordinate| bound the bands were derived for
@@ -361,7 +361,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
     if constexpr (NW > 1) {                       // pair-mask accumulators (OR-ed into with LDS atomics)
-        for (int k = sx; k < 4 * NW; k += WPE) pm[k * AG + at] = 0;
+        for (int k = sx; k < 5 * NW; k += WPE) pm[k * AG + at] = 0;
     }
     double warm = 0.0;
     if (use_lat) {
@@ -519,7 +519,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // every split evaluates 1/WPE of the agents j of each 64-agent group (branch-free, unrolled); the partial masks
     // are OR-combined through LDS so that every lane ends up with its complete "nearby" masks (split B also with the
     // candidate masks)
-    u64 nearbyN[NW], candN[NW], cand1N[NW];
+    u64 nearbyN[NW], candN[NW], cand1N[NW], cand2N[NW];
     {
         constexpr int JQ = JN / WPE;                  // agents j per split and 64-agent group
         static_assert(JQ * WPE == JN && JQ <= 32, "pair pass: JN must split evenly into <= 32 agents per split");
@@ -527,14 +527,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         // One compare + one add-with-carry per test: the compare's lane mask is the carry-in of acc = 2 acc + carry, so
         // after the JQ agents of this split bit (JQ-1-q) of acc is the answer for agent q; reversed and shifted into
         // place (agent j = sx*JQ + q) at the end.
-        unsigned a_nb[NW], a_cd[NW], a_c1[NW], a_ht[NW];
+        unsigned a_nb[NW], a_cd[NW], a_c1[NW], a_ht[NW], a_c2[NW];
         bool exc = false;
         for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
             FENCE();
             exc = false;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                a_nb[w] = 0; a_cd[w] = 0; a_c1[w] = 0; a_ht[w] = 0;
+                a_nb[w] = 0; a_cd[w] = 0; a_c1[w] = 0; a_ht[w] = 0; a_c2[w] = 0;
                 unsigned a_hi = 0;
 #pragma unroll
                 for (int q = 0; q < JQ; ++q) {
@@ -548,6 +548,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
                     a_cd[w] = shl1_or_mask(a_cd[w], __ballot(d2 < P.c_sen));
                     a_c1[w] = shl1_or_mask(a_c1[w], __ballot(d2 < P.c_close));
+                    if constexpr (NW > 2) a_c2[w] = shl1_or_mask(a_c2[w], __ballot(d2 < P.c_close2));   // wider pre-selection ring (N > 128: pays there)
                 }
                 exc = exc || (a_hi != a_nb[w]);        // some agent is not "nearby" by a hair (see the occupied-cell filter)
             }
@@ -566,7 +567,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 pm[((sx * PMK + 3) * NW + w) * AG + at] = place(a_ht[w]);
             }
             __syncthreads();
-            nearbyN[0] = 0; candN[0] = 0; cand1N[0] = 0;
+            nearbyN[0] = 0; candN[0] = 0; cand1N[0] = 0; cand2N[0] = 0;
 #pragma unroll
             for (int q = 0; q < WPE; ++q) nearbyN[0] |= pm[(q * PMK + 0) * AG + at];
             if (sx == SB) {
@@ -588,12 +589,13 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 atomicOr(&pm[(1 * NW + w) * AG + at], place(a_cd[w]));
                 atomicOr(&pm[(2 * NW + w) * AG + at], place(a_c1[w]));
                 atomicOr(&pm[(3 * NW + w) * AG + at], place(a_ht[w]));
+                atomicOr(&pm[(4 * NW + w) * AG + at], place(a_c2[w]));
             }
             __syncthreads();
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                nearbyN[w] = pm[(0 * NW + w) * AG + at]; candN[w] = 0; cand1N[w] = 0;
-                if (sx == SB) { candN[w] = pm[(1 * NW + w) * AG + at]; cand1N[w] = pm[(2 * NW + w) * AG + at]; }
+                nearbyN[w] = pm[(0 * NW + w) * AG + at]; candN[w] = 0; cand1N[w] = 0; cand2N[w] = 0;
+                if (sx == SB) { candN[w] = pm[(1 * NW + w) * AG + at]; cand1N[w] = pm[(2 * NW + w) * AG + at]; cand2N[w] = pm[(4 * NW + w) * AG + at]; }
             }
             if (sx == 0 && act) {
 #pragma unroll
@@ -625,6 +627,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 #pragma unroll
             for (int w = 0; w < NW; ++w) n1 += __popcll(c1[w]);
             const bool few = n1 >= P.topo;
+            if constexpr (NW > 2) {             // second, wider ring before falling back to everything within d_sen
+                u64 c2[NW]; int n2 = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) c2[w] = cand2N[w];
+                if (i < 64 * NW) c2[i >> 6] &= ~(1ull << (i & 63));
+#pragma unroll
+                for (int w = 0; w < NW; ++w) n2 += __popcll(c2[w]);
+                const bool some = n2 >= P.topo;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) cand[w] = some ? c2[w] : cand[w];
+            }
 #pragma unroll
             for (int w = 0; w < NW; ++w) cand[w] = few ? c1[w] : cand[w];
         }
@@ -1835,7 +1848,7 @@ void layout_t(KP &k)
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4 + (NW > 1 ? NW * 1536 : 0)), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)(NW == 1 ? WPE : 1) * 4 * NW * AG * 8));  // sidx | pm (per-split copies for N <= 64, one accumulator set above)
+    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)(NW == 1 ? WPE * 4 : 5) * NW * AG * 8));  // sidx | pm (per-split copies for N <= 64, one accumulator set above)
     k.off_partc = take((size_t)WPE * AG * 4);
     k.off_lat = take((size_t)EPB * 64 * (8 + 2));
     k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
@@ -1990,6 +2003,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     k.c_occ = cut_le(k.r_avoid / 2.0);                    // !(norm > r_avoid/2)       CPP:185
     k.c_avoid = cut_lt(k.r_avoid);                        // r_avoid > norm            CPP:482
     k.c_ball = cut_lt(k.size2);                           // d_center - sizes < 0      ENV:450-451
+    k.c_close2 = std::fmin(k.c_sen, (3.0 * k.r_avoid) * (3.0 * k.r_avoid));
     k.c_close = std::fmin(k.c_sen, (1.9 * k.r_avoid) * (1.9 * k.r_avoid));   // 1.9: fewest insertion trips on the 64-agent workload (measured)
     {   // fp32 pre-filter bands.  With |coordinates| <= S, a float-converted coordinate is off by <= 2^-24 S and
         // their float difference by another 2^-24 S at most: dr = 4 * 2^-24 * S bounds each component of the fp32
