@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- agent-steps/sec of the batched AssemblySwarm env step on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
-torch.distributed.run with one rank per GPU.  A "step" is one fused env step over one batch of synthetic
-environments (BASELINE.json: 64 agents x 4096 envs per GPU; weak scaling: 4096 envs on every rank, i.e.
-64 x 32768 at 8 GPUs).  Environments are independent, so ranks share nothing on the step path (no RCCL
-collective); torch.distributed is used only for the barrier and the max-over-ranks of the timing.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no torchrun environment this
+process SPAWNS the N ranks itself (fresh interpreters, before anything here touches the GPU; one LOCAL_RANK each);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it is one of the N ranks.  Either way
+`WORLD_SIZE` must equal `--gpus` or the run fails loudly.  A "step" is one fused env step over one batch of synthetic
+environments (BASELINE.json: 64 agents x 4096 envs per GPU; weak scaling: 4096 envs on every rank, i.e. 64 x 32768 at
+8 GPUs).  Environments are independent, so ranks share nothing on the step path (no RCCL collective);
+torch.distributed (through marl_llm_amd.dist_util) only provides the barrier and the max-over-ranks of the timing.
 
 Prints ONE JSON line on rank 0 with the contract's keys plus
-  "roofline":     HBM roofline of the step kernel (algorithmic bytes / HIP-event-timed launch duration / 8 TB/s)
-  "cpu_baseline": the reference's CPU path timed on this box's host cores on a bounded sample (rank 0, N=1)
+  "roofline":      HBM roofline of the step kernel: SURVEY section 8(d) algorithmic bytes / HIP-event-timed launch
+                   duration / 8 TB/s
+  "cpu_baseline":  the reference's CPU path (oracle/_ref: its own C++ compiled unmodified + a restatement of its numpy
+                   glue) timed on this box's host cores on a bounded sample: all cores (independent worker processes
+                   over envs, which is how the reference would use a host) and one core
+  "other_configs": kernel time + roofline fraction of the other shapes BASELINE.json names (N = 1 only)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,12 +33,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_SRC = os.path.join(ROOT, "marl_llm_amd", "csrc", "swarm_env.hip")
 
 
-def pmc_traffic(workload):
+def source_hash():
+    return hashlib.sha256(open(KERNEL_SRC, "rb").read()).hexdigest()[:16]
+
+
+def pmc_traffic(workload_key):
     """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
-    FETCH correction applied) and committed under profiles/: returned only when it was taken on this exact workload,
-    otherwise None (it cannot be measured from inside this process)."""
+    FETCH correction applied) and committed under profiles/ (tools/collect_profiles.sh).  Counters cannot be read from
+    inside this process, so the figure is returned only when the summary was taken on this exact workload AND on this
+    exact kernel source (sha256 of csrc/swarm_env.hip stored in the summary); otherwise None."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "final_pmc_summary.json"))):
@@ -36,7 +52,7 @@ def pmc_traffic(workload):
             d = json.load(open(f))
         except Exception:
             continue
-        if workload.startswith(d.get("_workload", "\0")):
+        if d.get("_workload") == workload_key and d.get("_source_sha256") == source_hash():
             best = float(d["_traffic_bytes_per_launch"])
     return best
 
@@ -52,158 +68,327 @@ def parse():
     ap.add_argument("--assemble-steps", type=int, default=100)
     ap.add_argument("--seed", type=int, default=226)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of each CPU baseline leg")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the all-cores leg (0 = host cores)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N>1 code path on a one-GPU box: every rank uses cuda:0 and the barrier / "
                          "max-over-ranks run over gloo (numbers from such a run are meaningless)")
+    ap.add_argument("--dry-spawn", action="store_true",
+                    help="N>1 plumbing check without a GPU: ranks join gloo, report rank / world, exit")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(sb, shapes, sy, r_avoid, n_agents, budget_s):
-    """Time the reference CPU path on a bounded sample of the SAME workload: the first few environments of
-    this batch, from the state the GPU run starts from, advanced with prior-policy actions (what the GPU loop
-    does).  kind = "reference": the reference's own libAssemblyEnv.so (compiled unmodified, oracle/_ref) driven
-    by a restatement of assembly.py's numpy glue; kind = "port": our plain-C oracle when _ref is not present."""
+# ----------------------------------------------------------------------------------------------------------------------
+# N > 1 without torchrun: spawn the ranks
+# ----------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """Start n fresh interpreters running this script as ranks 0..n-1 (children of this process, which never touches
+    the GPU; nothing is re-exec'd).  Rank 0 inherits stdout, so its ONE JSON line is this command's output."""
+    port = int(os.environ.get("MASTER_PORT", 0)) or free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 1500
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill(); code = 124
+        rc = rc or code
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        print(f"bench.py: a rank failed (exit code {rc})", file=sys.stderr)
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's CPU path on the host cores
+# ----------------------------------------------------------------------------------------------------------------------
+def host_cores():
+    """Cores this process may actually use: scheduler affinity, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_worker_main():
+    """One worker of the CPU baseline (started BEFORE the parent initialises the GPU; blocks on stdin until the parent
+    has the assembled state).  Steps its own slice of the batch's environments, one env at a time, `steps_per_env`
+    steps each with prior-policy actions, until the wall budget is spent.  Prints one JSON line."""
+    line = sys.stdin.readline()
+    if not line.strip():
+        return 0
+    job = json.loads(line)
     from oracle.oracle_py import Oracle, RefLib, ref_step
-    p, dp = [x.cpu().numpy() for x in sb.get_state()]
-    nei = sb.indices(False, False)["neighbor_index"].cpu().numpy()
+    z = np.load(job["state"])
     use_ref = RefLib.available()
     ref = RefLib() if use_ref else None
     orc = Oracle()
-    n_envs_sample, done_steps = 0, 0
-    t_used = 0.0
-    steps_per_env = 20
-    e = 0
-    while t_used < budget_s and e < sb.n_env:
-        g = np.ascontiguousarray(sy["cells"][e][:, : sy["n_g"][e]])
-        pe, dpe, ne = p[e].copy(), dp[e].copy(), nei[e].copy()
-        a = np.zeros((2, n_agents))
-        t0 = time.perf_counter()
-        for _ in range(steps_per_env):
+    n_a, ra, spe = int(job["n_agents"]), float(job["r_avoid"]), int(job["steps_per_env"])
+    w, nw = int(job["worker"]), int(job["workers"])
+    E = z["p"].shape[0]
+    done_steps, n_envs = 0, 0
+    t0 = time.perf_counter()
+    e = w
+    while time.perf_counter() - t0 < job["budget_s"] and e < E:
+        g = np.ascontiguousarray(z["cells"][e][:, : z["n_g"][e]])
+        pe, dpe, ne = z["p"][e].copy(), z["dp"][e].copy(), z["nei"][e].copy()
+        a = np.zeros((2, n_a))
+        for _ in range(spe):
             if use_ref:
-                s = ref_step(ref, pe, dpe, a, g, ne, float(sy["l_cell"][e]), r_avoid)
+                s = ref_step(ref, pe, dpe, a, g, ne, float(z["l_cell"][e]), ra)
             else:
-                s = orc.step(pe, dpe, a, g, ne, float(sy["l_cell"][e]), r_avoid)
+                s = orc.step(pe, dpe, a, g, ne, float(z["l_cell"][e]), ra)
             pe, dpe, ne = s["p"], s["dp"], s["neighbor_index"]
             a = s["a_prior"].astype(np.float32).astype(np.float64)
-        t_used += time.perf_counter() - t0
-        done_steps += steps_per_env
-        n_envs_sample += 1
-        e += 1
-    value = done_steps * n_agents / t_used
-    return {"value": value, "unit": "agent-steps/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"{n_envs_sample} envs x {steps_per_env} steps of the same {n_agents}-agent batch "
-                      f"(prior-policy actions), {t_used:.1f} s on 1 core; "
-                      + ("reference libAssemblyEnv.so + numpy glue" if use_ref else "plain-C oracle port")}
+        done_steps += spe; n_envs += 1
+        e += nw
+    print(json.dumps({"worker": w, "env_steps": done_steps, "envs": n_envs, "seconds": time.perf_counter() - t0,
+                      "kind": "reference" if use_ref else "port"}), flush=True)
+    return 0
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    if not torch.cuda.is_available():
-        print("bench.py: no HIP device visible; the env step has no CPU fallback", file=sys.stderr)
-        sys.exit(2)
-    if args.rehearse_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.rehearse_one_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+def start_cpu_workers(n):
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    return [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker"], env=env, stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, text=True) for _ in range(n)]
 
+
+def run_cpu_leg(workers, state_path, n_agents, r_avoid, budget_s, steps_per_env=20):
+    nw = len(workers)
+    for w, p in enumerate(workers):
+        p.stdin.write(json.dumps({"state": state_path, "n_agents": n_agents, "r_avoid": r_avoid, "budget_s": budget_s,
+                                  "steps_per_env": steps_per_env, "worker": w, "workers": nw}) + "\n")
+        p.stdin.flush()
+    res = []
+    for p in workers:
+        out, _ = p.communicate(timeout=budget_s * 6 + 120)
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    wall = max(r["seconds"] for r in res)
+    steps = sum(r["env_steps"] for r in res)
+    return {"value": steps * n_agents / wall, "envs": sum(r["envs"] for r in res), "seconds": wall, "kind": res[0]["kind"]}
+
+
+def cpu_baseline(sb, sy, r_avoid, n_agents, pool_all, pool_one, budget_s):
+    """Time the reference CPU path on a bounded sample of the SAME workload: environments of this batch, from the state
+    the GPU run starts from, advanced with prior-policy actions (what the GPU loop does).  kind = "reference": the
+    reference's own libAssemblyEnv.so (compiled unmodified, oracle/_ref) driven by a restatement of assembly.py's numpy
+    glue; kind = "port": our plain-C oracle when _ref is not present.  Two legs: one worker on one core, then P
+    independent worker processes (P = host cores), each stepping its own envs -- the reference itself is
+    single-threaded (c_lib.py:40-41 sets OMP_NUM_THREADS but the C++ has no pragma), so independent processes over
+    envs are how it would use a whole host."""
+    p, dp = [x.cpu().numpy() for x in sb.get_state()]
+    nei = sb.indices(False, False)["neighbor_index"].cpu().numpy()
+    fd, path = tempfile.mkstemp(suffix=".npz", prefix="bench_cpu_")
+    os.close(fd)
+    np.savez(path, p=p, dp=dp, nei=nei, cells=sy["cells"], n_g=sy["n_g"], l_cell=sy["l_cell"])
+    try:
+        one = run_cpu_leg(pool_one, path, n_agents, r_avoid, min(budget_s, 6.0))
+        allc = run_cpu_leg(pool_all, path, n_agents, r_avoid, budget_s)
+    finally:
+        os.unlink(path)
+    P = len(pool_all)
+    what = "reference libAssemblyEnv.so + numpy glue" if allc["kind"] == "reference" else "plain-C oracle port"
+    return {"value": allc["value"], "unit": "agent-steps/s", "cores": P, "kind": allc["kind"],
+            "sample": f"{allc['envs']} envs x 20 steps of the same {n_agents}-agent batch (prior-policy actions), "
+                      f"{P} independent worker processes for {allc['seconds']:.1f} s; {what}",
+            "one_core": {"value": one["value"], "cores": 1,
+                         "sample": f"{one['envs']} envs x 20 steps, {one['seconds']:.1f} s on 1 core"}}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the GPU measurement
+# ----------------------------------------------------------------------------------------------------------------------
+def survey_bytes(n_agents, n_g):
+    """B = 821 B per agent-step (action 8 r, p/dp 32 r+w as fp32, obs 768 w, reward 4 + done 1 +
+    prior 8 w) + the env's grid_center read once as fp32 (2 * n_g * 4 B), summed over the batch."""
+    return float(len(n_g)) * n_agents * 821.0 + 8.0 * float(np.sum(n_g))
+
+
+def measure(torch, n_a, E, state, steps, warmup, assemble_steps, seed, env_offset, device, barrier=None):
+    """Set up E envs of n_a agents on `device`, bring them to `state`, time `steps` steps.  Returns a dict (and the
+    SwarmBatch + inputs for the CPU baseline)."""
     from marl_llm_amd.batched import SwarmBatch
     from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
     from marl_llm_amd.synth import synthetic_batch
-
     shapes = synthetic_shape_set()
-    n_a, E = args.agents, args.envs
     r_avoid = r_avoid_for(n_a, shapes)
-    # weak scaling: every rank owns its own slice [rank*E, (rank+1)*E) of the global env range
-    sy = synthetic_batch(E, n_a, shapes, seed=args.seed, env_offset=rank * E)
-    sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=r_avoid,
-                    device=f"cuda:{local_rank}")
+    sy = synthetic_batch(E, n_a, shapes, seed=seed, env_offset=env_offset)
+    sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=r_avoid, device=device)
     sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"])
     sb.set_state(sy["p"], sy["dp"])
     sb.observe()
     dev = sb.device
-    gen = torch.Generator(device=dev); gen.manual_seed(args.seed + rank)
-    if args.state == "assembled":
+    gen = torch.Generator(device=dev); gen.manual_seed(seed + env_offset)
+    if state == "assembled":
         act = torch.zeros((E, n_a, 2), dtype=torch.float32, device=dev)
-        for _ in range(args.assemble_steps):          # untimed: assemble the swarm with the prior policy
+        for _ in range(assemble_steps):               # untimed: assemble the swarm with the prior policy
             _, _, _, act = sb.step(act)
+        pool = None
     else:
         pool = [torch.rand((E, n_a, 2), generator=gen, device=dev) * 2 - 1 for _ in range(8)]
         act = pool[0]
 
     def one_step(k, act):
-        if args.state == "assembled":
+        if state == "assembled":
             return sb.step(act)[3]                    # next action := this step's prior (device tensor, no copy)
         sb.step(pool[k % 8])
         return None
 
+    def timed():
+        nonlocal act
+        for k in range(warmup):
+            act = one_step(k, act)
+        torch.cuda.synchronize(dev)
+        if barrier is not None:
+            barrier()
+        torch.cuda.synchronize(dev)
+        sb.timer_start()                               # HIP events on the stream the kernel is launched on
+        t0 = time.perf_counter()
+        for k in range(steps):
+            act = one_step(k, act)
+        kernel_ms = sb.timer_stop()                    # synchronizes on the stop event
+        torch.cuda.synchronize(dev)
+        if barrier is not None:
+            barrier()
+        return time.perf_counter() - t0, kernel_ms
+
+    return sb, sy, r_avoid, timed
+
+
+def main():
+    args = parse()
+    if args.cpu_worker:
+        sys.exit(cpu_worker_main())
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr); sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))               # this process stays GPU-free; the children are the ranks
+
+    from marl_llm_amd import dist_util as du
+    rank, local_rank, world = du.rank_world()
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a mislabelled run", file=sys.stderr)
+        sys.exit(2)
+
+    if args.dry_spawn:                                 # plumbing rehearsal: no GPU anywhere
+        import torch
+        du.init(backend="gloo")
+        du.barrier()
+        top = du.max_over_ranks(float(rank))
+        ranks = du.gather_to_rank0(torch.tensor([[rank, local_rank, world]], dtype=torch.int64))
+        if rank == 0:
+            print(json.dumps({"dry_spawn": True, "n_gpus": world, "max_rank": top, "ranks": ranks[:, 0].tolist(),
+                              "local_ranks": ranks[:, 1].tolist()}), flush=True)
+        du.barrier()
+        du.shutdown()
+        return
+
+    # CPU-baseline workers start now, before this process initialises the GPU (they idle on stdin until the state exists)
+    pool_all = pool_one = None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_cpu:
+        pool_one = start_cpu_workers(1)
+        pool_all = start_cpu_workers(args.cpu_workers or host_cores())
+
+    import torch
+    if not torch.cuda.is_available():
+        for p in (pool_one or []) + (pool_all or []):
+            p.stdin.write("\n"); p.stdin.close()
+        print("bench.py: no HIP device visible; the env step has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    if args.rehearse_one_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    du.init(backend="gloo" if args.rehearse_one_gpu else "nccl", local_rank=local_rank)
+    barrier = du.barrier if world > 1 else None
+
+    n_a, E = args.agents, args.envs
+    # weak scaling: every rank owns its own slice [rank*E, (rank+1)*E) of the global env range
+    sb, sy, r_avoid, timed = measure(torch, n_a, E, args.state, args.steps, args.warmup, args.assemble_steps, args.seed,
+                                     rank * E, f"cuda:{local_rank}", barrier)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sb, shapes, sy, r_avoid, n_a, args.cpu_seconds)
-
-    for k in range(args.warmup):
-        act = one_step(k, act)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    sb.timer_start()                                   # HIP events on the stream the kernel is launched on
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        act = one_step(k, act)
-    kernel_ms = sb.timer_stop()                        # synchronizes on the stop event
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    if want_cpu:
+        cpu = cpu_baseline(sb, sy, r_avoid, n_a, pool_all, pool_one, args.cpu_seconds)
+    dt, kernel_ms = timed()
+    dt = du.max_over_ranks(dt, device="cpu" if (args.rehearse_one_gpu or world == 1) else sb.device)
     in_shape = float(sb.indices(False, False)["in_flags"].float().mean().item())
+    alg64 = sb.algorithmic_bytes_per_step()
+    sb.close()
+
+    others = []
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        for (oa, oe, ost, label) in ((32, 1024, "assembled", "BASELINE config 1"),
+                                     (64, 4096, "scatter", "headline shape, reset() state distribution, U(-1,1) actions"),
+                                     (256, 4096, "assembled", "BASELINE config 4 (dense O(N^2) neighbour path)"),
+                                     (64, 32768, "assembled", "BASELINE config 3's 8-GPU total on ONE GPU")):
+            osb, osy, _, otimed = measure(torch, oa, oe, ost, 50, 10, 100, args.seed, 0, f"cuda:{local_rank}")
+            odt, okms = otimed()
+            us = okms * 1e3 / 50
+            b = survey_bytes(oa, osy["n_g"])
+            others.append({"workload": f"assembly env, {oa} agents x {oe} envs, {ost} state", "what": label,
+                           "kernel_us": us, "agent_steps_per_s": oa * oe * 50 / odt,
+                           "algorithmic_bytes_per_launch": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+            osb.close()
+            del osb, osy
+            torch.cuda.empty_cache()
+
     if rank == 0:
         total_agent_steps = float(world) * E * n_a * args.steps
         value = total_agent_steps / dt
-        alg_bytes = sb.algorithmic_bytes_per_step()
         launch_s = kernel_ms * 1e-3 / args.steps
-        achieved = alg_bytes / launch_s / 1e9
-        workload = (f"assembly env, {n_a} agents x {E} envs per GPU ({n_a} x {E * world} total), assembled state, "
-                    f"prior-policy actions" if args.state == "assembled" else
-                    f"assembly env, {n_a} agents x {E} envs per GPU ({n_a} x {E * world} total), scatter state, "
-                    f"U(-1,1) actions")
+        alg = survey_bytes(n_a, sy["n_g"])
+        achieved = alg / launch_s / 1e9
+        what = "assembled state, prior-policy actions" if args.state == "assembled" else "scatter state, U(-1,1) actions"
+        workload = f"assembly env, {n_a} agents x {E} envs per GPU ({n_a} x {E * world} total), {what}"
         out = {
             "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 (state, every index / flag / reward decision) + f32 (obs, prior, action I/O, pre-filters)",
             "data": "synthetic",
             "config": {"workload": workload,
                        "agents": n_a, "envs_per_gpu": E, "envs_total": E * world, "obs_dtype": "f32",
                        "state_dtype": "f64", "in_shape_fraction": round(in_shape, 3), "seed": args.seed,
                        "parallelism": f"env-sharded x{world}, no collective on the step path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(workload.split(" (")[0] + ", assembled state" if args.state == "assembled" else "-"),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(f"assembly env, {n_a} agents x {E} envs per GPU, {args.state} state"),
                          "kernel": "k_env<%d,float,true>" % max(8, 1 << (n_a - 1).bit_length()), "kernel_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg,
+                         "algorithmic_bytes_note": "SURVEY 8(d): 821 B per agent-step + 8 B per target cell per env",
+                         "bytes_per_launch_this_build_dtypes": alg64,
+                         "kernel_source_sha256": source_hash()},
         }
         if cpu is not None:
             cpu["gpu_over_cpu"] = value / cpu["value"]
+            cpu["one_core"]["gpu_over_cpu"] = value / cpu["one_core"]["value"]
             out["cpu_baseline"] = cpu
+        if others:
+            out["other_configs"] = others
         print(json.dumps(out), flush=True)
-    sb.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    du.barrier()
+    du.shutdown()
 
 
 if __name__ == "__main__":

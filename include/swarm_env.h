@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SWARM_ABI_VERSION 2
+#define SWARM_ABI_VERSION 3
 
 enum { SWARM_F32 = 0, SWARM_F64 = 1, SWARM_BF16 = 2 };
 
@@ -125,6 +125,9 @@ int  swarm_set_shapes(swarm_env_t *h, int n_shapes, const double *shape_cells, c
 int  swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_offset, void *obs);
 int  swarm_get_state(swarm_env_t *h, double *p, double *dp);
 int  swarm_get_cells(swarm_env_t *h, double *cells, int32_t *n_g);        /* [E][2][n_cells_max], [E]; host or device */
+/* Shape index each env drew in the last swarm_reset (assembly.py:160 `rand_shape_index`), [E] host or device; -1 for envs whose
+ * cells were set through swarm_set_cells.  The host needs it for l_cell / shape_frequency (assembly.py:161-163). */
+int  swarm_get_shape_index(swarm_env_t *h, int32_t *shape_index);
 
 /* Recompute observations and the obs-derived caches (neighbor_index, in_flags, nearest cell) from the
  * current state: what AssemblySwarmEnv.reset() does with its final _get_obs() (assembly.py:221).

@@ -25,11 +25,11 @@ class SwarmError(RuntimeError):
 
 _LIB = None
 
-ABI_VERSION = 2            # include/swarm_env.h SWARM_ABI_VERSION
+ABI_VERSION = 3            # include/swarm_env.h SWARM_ABI_VERSION
 BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", "swarm_destroy", "swarm_last_error",
                    "swarm_set_stream", "swarm_synchronize", "swarm_obs_dim", "swarm_set_cells", "swarm_set_state",
                    "swarm_get_state", "swarm_observe", "swarm_step", "swarm_get_indices",
-                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_metrics", "swarm_rule_action")
+                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_get_shape_index", "swarm_metrics", "swarm_rule_action")
 POLICY_SYMBOLS = ("swarm_policy_create", "swarm_policy_destroy", "swarm_policy_forward", "swarm_policy_forward_bf16", "swarm_policy_last_error")   # include/swarm_policy.h
 LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior")
 
@@ -57,6 +57,7 @@ def load():
     lib.swarm_set_state.argtypes = [vp, vp, vp]; lib.swarm_set_state.restype = i32
     lib.swarm_get_state.argtypes = [vp, vp, vp]; lib.swarm_get_state.restype = i32
     lib.swarm_get_cells.argtypes = [vp, vp, vp]; lib.swarm_get_cells.restype = i32
+    lib.swarm_get_shape_index.argtypes = [vp, vp]; lib.swarm_get_shape_index.restype = i32
     lib.swarm_metrics.argtypes = [vp, vp]; lib.swarm_metrics.restype = i32
     lib.swarm_rule_action.argtypes = [vp, vp]; lib.swarm_rule_action.restype = i32
     lib.swarm_policy_create.argtypes = [vp] * 8 + [i32] * 4 + [ctypes.POINTER(vp)]; lib.swarm_policy_create.restype = i32

@@ -130,6 +130,13 @@ class SwarmBatch:
                                                               n_g.ctypes.data_as(ctypes.c_void_p)))
         return cells, n_g
 
+    def get_shape_index(self):
+        """[E] int32 numpy: the shape index every env drew in the last device-side reset (-1: cells set by hand)."""
+        out = np.empty(self.n_env, np.int32)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_get_shape_index(self.handle, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def set_state(self, p, dp):
         """p, dp [E, 2, N] float64 (numpy or torch)."""
         keep = []

@@ -1433,7 +1433,7 @@ __host__ __device__ inline double reset_u01(unsigned long long key, unsigned k)
 
 __global__ void __launch_bounds__(256)
 k_reset(const KP P, const ShapeSet S, const unsigned long long seed, const unsigned long long episode,
-        const long long env_offset, double *cells_out, int *ng_out, double *cin_out, LatEnv *lat_out)
+        const long long env_offset, double *cells_out, int *ng_out, double *cin_out, LatEnv *lat_out, int *shape_out)
 {
     const int e = blockIdx.x, tid = threadIdx.x;
     const unsigned long long key = mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (episode + 1)) ^ (unsigned long long)(env_offset + e));
@@ -1453,7 +1453,7 @@ k_reset(const KP P, const ShapeSet S, const unsigned long long seed, const unsig
         gx[c] = x; gy[c] = y;
     }
     if (tid == 0) {
-        ng_out[e] = ng; cin_out[e] = S.c_in[s];
+        ng_out[e] = ng; cin_out[e] = S.c_in[s]; shape_out[e] = s;
         LatEnv L = S.lat[s];
         if (L.nrows > 0) {          // rotate / shift the shape's lattice: u' = R u, v' = R v, o' = R o + offset
             // shape-frame basis from the stored inverse basis: u = uxi / |uxi|^2
@@ -1722,6 +1722,7 @@ struct swarm_env {
     int n_shapes;
     double *d_shape_cells, *d_shape_l, *d_shape_cin;
     int *d_shape_ng;
+    int *d_shape_idx;              // [E] shape index drawn by the last swarm_reset (-1 before / after swarm_set_cells)
     LatEnv *d_shape_lat;
     bool shapes_lattice; float shapes_rmax, shapes_cmax; int shapes_ncols;
     std::vector<char> lat_ok;      // per env: cells are a lattice subset
@@ -1975,7 +1976,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     for (int &a : h->attr_smem) a = -1;
     h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr; h->d_cells_xy = nullptr;
     h->d_lat = nullptr;
-    h->n_shapes = 0; h->d_shape_cells = h->d_shape_l = h->d_shape_cin = nullptr; h->d_shape_ng = nullptr; h->d_shape_lat = nullptr;
+    h->n_shapes = 0; h->d_shape_cells = h->d_shape_l = h->d_shape_cin = nullptr; h->d_shape_ng = nullptr; h->d_shape_lat = nullptr; h->d_shape_idx = nullptr;
     h->shapes_lattice = false; h->shapes_rmax = h->shapes_cmax = 0.0f; h->shapes_ncols = 0;
     h->lat_ok.assign((size_t)cfg->n_env, 0);
     h->lat_R.assign((size_t)cfg->n_env, 0.0f); h->lat_Rc.assign((size_t)cfg->n_env, 0.0f);
@@ -2058,11 +2059,12 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     alloc((void **)&h->d_p, E * 2 * N * 8); alloc((void **)&h->d_dp, E * 2 * N * 8);
     alloc((void **)&h->d_cells, E * 2 * (size_t)k.ng_max * 8); alloc((void **)&h->d_cin, E * 8);
     alloc((void **)&h->d_cells_xy, E * (size_t)k.ng_max * 16);
-    alloc((void **)&h->d_ng, E * 4);
+    alloc((void **)&h->d_ng, E * 4); alloc((void **)&h->d_shape_idx, E * 4);
     alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
     alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_hit, E * N * 8 * (size_t)std::max(1, h->npad / 64));
     if (a == hipSuccess) a = hipMemset(h->d_ng, 0, E * 4);
+    if (a == hipSuccess) a = hipMemset(h->d_shape_idx, 0xFF, E * 4);
     if (a == hipSuccess) a = hipMemset(h->d_nei, 0xFF, E * N * (size_t)k.topo * 4);
     if (a == hipSuccess) a = hipMemset(h->d_near, 0, E * N * 4);
     if (a == hipSuccess) a = hipMemset(h->d_inflag, 0, E * N * 4);
@@ -2092,7 +2094,7 @@ int swarm_destroy(swarm_env_t *h)
         (void)hipStreamSynchronize(h->stream);
         (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin); (void)hipFree(h->d_cells_xy);
         (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag); (void)hipFree(h->d_hit);
-        (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat);
+        (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat); (void)hipFree(h->d_shape_idx);
         (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -2139,6 +2141,7 @@ int swarm_set_cells(swarm_env_t *h, int env_begin, int count, const double *cell
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_ng + env_begin, n_g, (size_t)count * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_shape_idx + env_begin, 0xFF, (size_t)count * 4, h->stream));   // no longer a shape of the set
     HIP_TRY(h, hipMemcpyAsync(h->d_cin + env_begin, cin.data(), (size_t)count * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));           // cin is a host temporary
     {   // lattice detection on a host copy of what was uploaded (`cells` may be a device pointer)
@@ -2226,7 +2229,7 @@ int swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_off
     S.n_shapes = h->n_shapes; S.cells = h->d_shape_cells; S.n_g = h->d_shape_ng; S.l_cell = h->d_shape_l;
     S.c_in = h->d_shape_cin; S.lat = h->d_shape_lat;
     hipLaunchKernelGGL(k_reset, dim3(h->cfg.n_env), dim3(256), 0, h->stream, h->kp, S, (unsigned long long)seed,
-                       (unsigned long long)episode, (long long)env_offset, h->d_cells, h->d_ng, h->d_cin, h->d_lat);
+                       (unsigned long long)episode, (long long)env_offset, h->d_cells, h->d_ng, h->d_cin, h->d_lat, h->d_shape_idx);
     HIP_TRY(h, hipGetLastError());
     {
         const size_t n = (size_t)h->cfg.n_env * h->kp.ng_max;
@@ -2281,6 +2284,15 @@ int swarm_get_cells(swarm_env_t *h, double *cells, int32_t *n_g)
     DeviceGuard g(h->device);
     if (cells) HIP_TRY(h, hipMemcpyAsync(cells, h->d_cells, (size_t)h->cfg.n_env * 2 * h->kp.ng_max * 8, hipMemcpyDefault, h->stream));
     if (n_g) HIP_TRY(h, hipMemcpyAsync(n_g, h->d_ng, (size_t)h->cfg.n_env * 4, hipMemcpyDefault, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWARM_OK;
+}
+
+int swarm_get_shape_index(swarm_env_t *h, int32_t *shape_index)
+{
+    if (!h || !shape_index) return SWARM_ERR_INVALID;
+    DeviceGuard g(h->device);
+    HIP_TRY(h, hipMemcpyAsync(shape_index, h->d_shape_idx, (size_t)h->cfg.n_env * 4, hipMemcpyDefault, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SWARM_OK;
 }

@@ -12,9 +12,12 @@ def rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
-    rank, local_rank, world = rank_world()
+def init(backend=None, local_rank=None):
+    """Initialise the default process group from the torchrun-style environment (RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT; bench.py sets the same variables when it spawns the ranks itself).  No-op for world size 1.
+    `local_rank` overrides LOCAL_RANK as the device ordinal handed to RCCL (one-GPU rehearsals use 0 everywhere)."""
+    rank, env_local, world = rank_world()
+    local_rank = env_local if local_rank is None else local_rank
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -23,6 +26,11 @@ def init(backend=None):
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, **kw)
     return rank, local_rank, world
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def shard_range(n_total, rank, world):

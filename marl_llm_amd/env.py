@@ -190,7 +190,9 @@ class AssemblySwarmEnv(_EnvBase):
                 self._shapes_uploaded = True
             obs = b.reset(self._seed, self._episode, getattr(self, "env_offset", 0))
             self._cells, self._n_g = b.get_cells()
-            self._l_cell = np.zeros(self.n_envs)         # per-env l_cell stays on the device in this mode
+            self.shape_index = b.get_shape_index().astype(np.int64)      # which shape the device drew per env (:160)
+            self._l_cell = np.asarray(self.l_cells, dtype=np.float64)[self.shape_index]
+            np.add.at(self.shape_frequency, self.shape_index, 1)
             self._cells_dirty = False
             return obs
         s = self._sample_reset()
@@ -208,14 +210,24 @@ class AssemblySwarmEnv(_EnvBase):
     def reset(self):
         return self._obs_to_numpy(self.reset_tensor())
 
-    # ------------------------------------------------------------------ step (assembly.py:487-666)
-    def step_tensor(self, action):
-        """action [E, N, 2] device tensor -> (obs [E,N,D], reward [E,N], done [E,N] uint8, a_prior [E,N,2] | None)."""
+    def _flush_cells(self):
+        """Upload target cells that were assigned through the attribute setters and refresh the obs-derived caches.
+
+        The reference's eval script switches the target shape by assigning env.env.{l_cell, n_g, grid_center}
+        (eval_assembly.py:34-57) and reads the wrapper metrics right after, BEFORE the next step (:154-162); its env
+        holds plain attributes, so every reader sees the new cells at once.  Here the cells live on the device: every
+        reader of device state (step, metrics, indices, rule action) calls this first."""
         b = self._backend()
-        if self._cells_dirty:          # eval-time shape switch (eval_assembly.py:34-57): refresh cells + caches
+        if self._cells_dirty:
             b.set_cells(self._cells, self._n_g, self._l_cell)
             b.observe()
             self._cells_dirty = False
+        return b
+
+    # ------------------------------------------------------------------ step (assembly.py:487-666)
+    def step_tensor(self, action):
+        """action [E, N, 2] device tensor -> (obs [E,N,D], reward [E,N], done [E,N] uint8, a_prior [E,N,2] | None)."""
+        b = self._flush_cells()
         self.simulation_time += self.dt
         if self.agent_strategy == "rule":          # assembly.py:530-601: the expert controller replaces the passed action
             action = b.rule_action()
@@ -269,13 +281,18 @@ class AssemblySwarmEnv(_EnvBase):
         p = np.asarray(p, np.float64); dp = np.asarray(dp, np.float64)
         if p.ndim == 2:
             p = p.reshape(2, E, N).transpose(1, 0, 2); dp = dp.reshape(2, E, N).transpose(1, 0, 2)
-        b = self._backend()
+        b = self._flush_cells() if getattr(self, "_cells", None) is not None else self._backend()
         b.set_state(np.ascontiguousarray(p), np.ascontiguousarray(dp))
         return self._obs_to_numpy(b.observe())
 
     def indices(self):
         """neighbor_index / in_flags / sensed_index / occupied_index of the current state (numpy)."""
-        return {k: v.cpu().numpy() for k, v in self._backend().indices().items()}
+        return {k: v.cpu().numpy() for k, v in self._flush_cells().indices().items()}
+
+    def metrics_tensor(self):
+        """[E, 3] float64 device tensor: coverage_rate, distribution_uniformity, voronoi_based_uniformity per env
+        (assembly_wrapper.py:48-128) of the current state and the CURRENT target cells."""
+        return self._flush_cells().metrics()
 
     # grid_center / n_g / l_cell: readable and writable like the reference's attributes (env 0 when E > 1)
     @property
@@ -310,7 +327,9 @@ class AssemblySwarmEnv(_EnvBase):
 
     # ------------------------------------------------------------------ misc gym surface
     def render(self, mode="human"):
-        raise NotImplementedError("rendering is outside the step path (SURVEY.md section 8: out of scope)")
+        """No-op.  The reference draws the swarm with matplotlib (assembly.py:668-747); drawing is not on the step path,
+        but train_assembly.py:94-95 and eval_assembly.py:147 call it inside their loops, so it must exist and return."""
+        return None
 
     def close(self):
         if self._batch is not None:
@@ -344,13 +363,16 @@ class AssemblySwarmWrapper(_WrapperBase):
 
     # evaluation metrics (assembly_wrapper.py:48-128), computed on the device; env 0 when several envs are batched
     def coverage_rate(self):
-        return float(self.env._backend().metrics()[0, 0].item())
+        return float(self.env.metrics_tensor()[0, 0].item())
 
     def distribution_uniformity(self):
-        return float(self.env._backend().metrics()[0, 1].item())
+        return float(self.env.metrics_tensor()[0, 1].item())
 
     def voronoi_based_uniformity(self):
-        return float(self.env._backend().metrics()[0, 2].item())
+        return float(self.env.metrics_tensor()[0, 2].item())
+
+    def render(self, mode="human", **kw):
+        return self.env.render(mode=mode, **kw)
 
     def reset(self, **kw):
         return self.env.reset(**kw)
@@ -366,6 +388,26 @@ def make_args(n_a=30, results_file=None, **over):
              results_file=results_file, video=False)
     d.update(over)
     return types.SimpleNamespace(**d)
+
+
+class _Made:
+    """What `gym.make(id)` hands back as far as the reference's callers use it: they take `.unwrapped` at once
+    (train_assembly.py:49, eval_assembly.py:96; the TimeLimit wrapper gym adds is thereby stripped)."""
+
+    def __init__(self, env):
+        self.env = env
+
+    @property
+    def unwrapped(self):
+        return self.env
+
+
+def make(env_id="AssemblySwarm-v0", **kw):
+    """`gym.make('AssemblySwarm-v0')` for hosts without a gym package (cus_gym/gym/envs/__init__.py:14-19 registers
+    exactly this id for the assembly env).  With a gym module present use :func:`register` and gym.make instead."""
+    if env_id != "AssemblySwarm-v0":
+        raise KeyError("unknown environment id %r (this package provides AssemblySwarm-v0)" % (env_id,))
+    return _Made(AssemblySwarmEnv(**kw))
 
 
 def register(gym_module=None, n_envs=1, **kw):

@@ -57,3 +57,26 @@ def test_shard_range_covers_everything():
             assert all(cuts[k][1] == cuts[k + 1][0] for k in range(world - 1))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun) must itself produce two ranks: --dry-spawn runs the same spawn /
+    dist_util init / barrier / max-over-ranks / gather plumbing over gloo and exits before any GPU use."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-spawn"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == [0, 1] and d["local_ranks"] == [0, 1] and d["max_rank"] == 1.0
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """Under a launcher that gives WORLD_SIZE != --gpus the run must fail loudly instead of printing n_gpus of its own."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-spawn"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in out.stderr

@@ -28,7 +28,6 @@ def test_golden_trajectory_through_env_api(path, shapes):
     e.r_avoid = float(z["r_avoid"])
     e.grid_center = z["grid"]; e.l_cell = float(z["l_cell"])
     assert e.r_avoid == env.r_avoid
-    e._backend().set_cells(e._cells, e._n_g, e._l_cell); e._cells_dirty = False
     e.set_state(z["p"][0], z["dp"][0])
     for t in range(T):
         obs, rew, done, info, pri = env.step(z["a"][t])
@@ -58,7 +57,6 @@ def test_flattened_multi_env_equals_separate_envs(shapes):
         one.reset()
         e = one.env
         e.grid_center = cells[k][:, : n_g[k]]; e.l_cell = float(l_cell[k])
-        e._backend().set_cells(e._cells, e._n_g, e._l_cell); e._cells_dirty = False
         sl = slice(k * N, (k + 1) * N)
         o0 = e.set_state(p0[:, sl], dp0[:, sl])
         assert np.array_equal(o0, obs0[:, sl])
