@@ -65,6 +65,7 @@ struct LatEnv {
 struct KP {
     int n_env, n_a, ng_max, ngw, topo, g_max, occ_max, obs_dim;
     int with_self, periodic, boundary, with_prior, export_idx;
+    int export_small;          // also write neighbor_index / nearest cell / in_flags to HBM (export launches only: the step itself keeps them in LDS)
     int cxy_stride;            // double2 elements per env in LDS
     int cxq_stride;            // floats per env in the fp32 pair layout
     int g_stride;              // int16 elements per agent row in LDS
@@ -99,6 +100,7 @@ struct KP {
     const int *n_g;
     const double *c_in;
     int *exp_sensed, *exp_occ;
+    void *prior_next;          // [E][N] pairs of the handle's obs dtype: the prior policy of the next step (written by every pass)
     long long *stamps;         // diagnostic build only (-DSWARM_STAMPS): per-block phase clocks
 };
 
@@ -113,6 +115,13 @@ template <> struct Pair<__bf16> { typedef bf2v type; };
 // output conversion of an exact fp64 value: one rounding for f64 / f32; bf16 = the f32 value rounded again (RNE), i.e. what a
 // consumer gets from `obs_f32.to(bfloat16)`
 template <typename OT> __device__ __forceinline__ OT to_out(double v) { return (OT)v; }
+// streaming store of one observation pair: the observation block (768 B per agent and step, written once, read by another
+// kernel) would otherwise sweep the target cells, lattice rows and agent state of every environment out of the L2 between
+// launches; the non-temporal hint keeps those resident for the next step's gathers
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_nt(float2 *dst, float2 v) { f2v t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(dst)); }
+__device__ __forceinline__ void store_nt(double2 *dst, double2 v) { d2v t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<d2v *>(dst)); }
+__device__ __forceinline__ void store_nt(bf2v *dst, bf2v v) { __builtin_nontemporal_store(v, dst); }
 template <> __device__ __forceinline__ __bf16 to_out<__bf16>(double v) { return (__bf16)(float)v; }
 
 __device__ __forceinline__ void wrap_rel(double &x, double &y, double wh, double hh)
@@ -170,7 +179,8 @@ __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
 #define EXIT_AT(k) do { if (P.dbg_phase == 15 && P.dbg_extra == (k)) return; } while (0)
 
 #ifdef SWARM_STAMPS
-#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); stamp_t[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// written straight to global memory by lane 0 of every wave (no registers held across the kernel)
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (P.stamps != nullptr && (threadIdx.x & 63) == 0) P.stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 24 + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
@@ -263,10 +273,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     unsigned *cov = reinterpret_cast<unsigned *>(smem + P.off_cov);      // [EPB][ngw+1] cells within r_avoid/2 of ANY agent
     int *sflag = reinterpret_cast<int *>(smem + P.off_flag);             // [AG] per-lane exception flags
 
-#ifdef SWARM_STAMPS
-    long long stamp_t[16];
-    for (int k = 0; k < 16; ++k) stamp_t[k] = 0;
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     STAMP(0);
     const int at = tid % AG;                 // agent thread
@@ -313,12 +319,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const size_t sbase = (size_t)es * 2 * n_a;
     double px = __builtin_nan(""), py = __builtin_nan(""), vx = 0.0, vy = 0.0;   // inactive lanes: NaN positions,
     double ax = 0.0, ay = 0.0;                                                    // every comparison is false
-    int pj[kTopoMax]; int ncell = 0, inf = 0;
-#pragma unroll
-    for (int k = 0; k < kTopoMax; ++k) pj[k] = -1;
     u64 hit0[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) hit0[w] = 0;
+    OT2 pri_now; pri_now.x = to_out<OT>(0.0); pri_now.y = to_out<OT>(0.0);
+    const bool copy_prior = DO_STEP && P.with_prior && a_prior != nullptr;
     if (sx == 0 && act) {
         if (DO_STEP) {
 #pragma unroll
@@ -329,14 +334,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         if (DO_STEP) {
             if (act_f64) { const size_t ab = ((size_t)e * n_a + i) * 2; ax = ((const double *)action)[ab]; ay = ((const double *)action)[ab + 1]; }
             else { const float2 af = reinterpret_cast<const float2 *>(action)[(size_t)e * n_a + i]; ax = (double)af.x; ay = (double)af.y; }
+            // the prior policy of THIS step (CPP:1061-1196 via ENV:605-624) is a function of the pre-integration state and
+            // of the neighbour list / nearest cell of the previous observation: the previous launch evaluated it at its end,
+            // where all of that sat in registers and LDS, and left it in HBM -- here it is only handed to the caller
+            if (copy_prior) pri_now = reinterpret_cast<const OT2 *>(P.prior_next)[(size_t)e * n_a + i];
         }
-    }
-    if (DO_STEP && sx == SB && act && P.with_prior) {
-        ncell = P.near_cell[(size_t)e * n_a + i];
-        inf = P.in_flag[(size_t)e * n_a + i];
-#pragma unroll
-        for (int k = 0; k < kTopoMax; ++k)
-            if (k < P.topo) pj[k] = P.nei[((size_t)e * n_a + i) * P.topo + k];
     }
     // ---- generic (non-lattice) mode: stage an fp32 copy of the target cells (ENV: grid_center (2, n_g)) in LDS, laid
     // out per pair of cells {xa, xb, ya, yb} for packed arithmetic, padded with a sentinel (fp32: +inf).  The lattice
@@ -364,10 +366,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int k = sx; k < 5 * NW; k += WPE) pm[k * AG + at] = 0;
     }
     double warm = 0.0;
+    if (sx == 0) sflag[at] = 0;
     if (use_lat) {
+        for (int q = tid; q < EPB * 64; q += T) {
+            const int ek0 = blockIdx.x * EPB + (q >> 6);
+            const LatEnv &Lq = P.lat[ek0 < P.n_env ? ek0 : P.n_env - 1];
+            lrm[q] = Lq.rowmask[q & 63]; lrs[q] = Lq.rowstart[q & 63];
+        }
         // lattice mode gathers the fp64 cells from global memory (nearest-cell merge, reward weights, observation
         // values): one coalesced pass over this workgroup's cells up front brings them into L2 / L1 and the TLB, so the
-        // later per-lane gathers hit instead of each paying a scattered HBM access.  The values are only summed.
+        // later per-lane gathers hit instead of each paying a scattered HBM access.  The values are only summed, and
+        // nothing waits for them before the nearest-cell merge (they are issued last, so earlier loads retire first).
         for (int k = 0; k < EPB; ++k) {
             const int ek0 = blockIdx.x * EPB + k;
             const int ek = ek0 < P.n_env ? ek0 : P.n_env - 1;
@@ -378,57 +387,15 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
         for (int w = sx; w <= W; w += WPE) reinterpret_cast<unsigned *>(smem + P.off_cmask)[w * AG + at] = 0;   // rank-select bits (region unused until then)
         for (int q = tid; q < EPB * (P.ngw + 1); q += T) cov[q] = 0;
-        for (int q = tid; q < EPB * 64; q += T) {
-            const int ek0 = blockIdx.x * EPB + (q >> 6);
-            const LatEnv &Lq = P.lat[ek0 < P.n_env ? ek0 : P.n_env - 1];
-            lrm[q] = Lq.rowmask[q & 63]; lrs[q] = Lq.rowstart[q & 63];
-        }
-        if (sx == 0) sflag[at] = 0;
     }
-    asm volatile("" :: "v"(warm));       // keeps the warming loads alive; they retire here, where the barrier waits anyway
-    __syncthreads();
-    STAMP(1);
-    EXIT_AT(0);
-
-    if (DO_STEP) {
-        if (sx == SB && SB != 0) { px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at]; }
-        double npx = px, npy = py, nvx = vx, nvy = vy;
-        if (sx == SB) for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
-            FENCE();
-            // ---- prior policy on the PRE-integration state with the previous neighbour list:
-            // CPP:1061-1196 via ENV:605-624.  The nearest cell / in-shape flag of the pre-integration
-            // position are the ones the previous observation pass cached.
-            if (P.with_prior && act && a_prior != nullptr) {
-                double tx, ty;
-                if (inf) { tx = px - px; ty = py - py; }
-                else { const double2 g = cell64(ncell); tx = g.x - px; ty = g.y - py; }
-                double qx = 0.0, qy = 0.0;
-                const double dt_ = sqrt(tx * tx + ty * ty);
-                if (dt_ > 0) { qx += 2.0 * tx / dt_; qy += 2.0 * ty / dt_; }
-                double avx = 0.0, avy = 0.0; int cnt = 0;
-#pragma unroll
-                for (int k = 0; k < kTopoMax; ++k) {
-                    const int j = pj[k];
-                    if (j < 0) continue;
-                    const int tj = el * NPAD + j;
-                    const double x = px - sp[tj], y = py - sp[AG + tj];
-                    const double d = sqrt(x * x + y * y);
-                    if (d > 0 && d < P.r_avoid) {
-                        const double ux = x / d, uy = y / d;
-                        const double factor = 3.0 * (P.r_avoid / d - 1.0);
-                        qx += factor * ux; qy += factor * uy;
-                    }
-                    avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt;
-                }
-                if (cnt > 0) {
-                    avx /= cnt; avy /= cnt;
-                    qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
-                }
-                OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
-                reinterpret_cast<OT2 *>(a_prior)[(size_t)e * n_a + i] = o;
-            }
-        }
-        if (sx == 0) for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
+    // ---- forces + integration (split A).  For N <= 64 split A is ONE wavefront holding every agent of its environment(s):
+    // it parks the old positions in LDS for its own contact-spring loop (a wavefront's LDS operations execute in order,
+    // so no workgroup barrier is needed between its write and its read), integrates, and overwrites them with the new
+    // state -- the other splits meanwhile initialise LDS, and ONE barrier publishes everything.  For N > 64 split A
+    // spans several wavefronts and keeps the write / barrier / read / barrier / write / barrier sequence.
+    double npx = px, npy = py, nvx = vx, nvy = vy;
+    auto forces_integrate = [&]() {
+        for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
             FENCE();
             // ---- ball-to-ball contact spring: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all).
             // Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped when
@@ -493,17 +460,38 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 if (npy > P.by1) npy -= 2 * P.h_half;
             }
         }
-        STAMP(11);
-        __syncthreads();                 // every lane is done with the old positions in LDS
-        STAMP(12);
-        if (sx == 0) {
-            sp[at] = npx; sp[AG + at] = npy; sp[2 * AG + at] = nvx; sp[3 * AG + at] = nvy;
-            if (act) {
-                P.p[sbase + i] = npx; P.p[sbase + n_a + i] = npy;
-                P.dp[sbase + i] = nvx; P.dp[sbase + n_a + i] = nvy;
-            }
+    };
+    auto publish_new_state = [&]() {
+        sp[at] = npx; sp[AG + at] = npy; sp[2 * AG + at] = nvx; sp[3 * AG + at] = nvy;
+        if (act) {
+            P.p[sbase + i] = npx; P.p[sbase + n_a + i] = npy;
+            P.dp[sbase + i] = nvx; P.dp[sbase + n_a + i] = nvy;
+            if (copy_prior) store_nt(&reinterpret_cast<OT2 *>(a_prior)[(size_t)e * n_a + i], pri_now);
+        }
+    };
+    if constexpr (NW == 1) {
+        if (DO_STEP && sx == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // old positions (written above) before the reads below
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            forces_integrate();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            publish_new_state();
         }
         __syncthreads();
+        STAMP(1);
+        EXIT_AT(0);
+    } else {
+        __syncthreads();
+        STAMP(1);
+        EXIT_AT(0);
+        if (DO_STEP) {
+            if (sx == 0) forces_integrate();
+            __syncthreads();                 // every lane is done with the old positions in LDS
+            if (sx == 0) publish_new_state();
+            __syncthreads();
+        }
     }
     px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at];
     STAMP(2);
@@ -553,6 +541,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 exc = exc || (a_hi != a_nb[w]);        // some agent is not "nearby" by a hair (see the occupied-cell filter)
             }
         }
+        STAMP(14);
         if (use_lat && exc) atomicOr(&sflag[at], 1);   // resolve the occupied-cell filter of this agent exactly
         auto place = [&](unsigned acc) -> u64 { return (u64)(__brev(acc) >> (32 - JQ)) << (sx * JQ); };
         if constexpr (NW == 1) {
@@ -608,6 +597,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     const u64 nearby1 = nearbyN[0];
+    STAMP(15);
     EXIT_AT(2);
     if (sx == SB) for (int rep = 0, reps = REPS(10); rep < reps; ++rep) {
         FENCE();
@@ -670,7 +660,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const bool used = k < P.topo && nj[k] >= 0;
             snei[at * kNeiStride + k] = (short)(used ? nj[k] : -1);
             if (used && nd[k] < P.c_avoid) collision = true;
-            if (act && k < P.topo) P.nei[((size_t)e * n_a + i) * P.topo + k] = used ? nj[k] : -1;
+            if (P.export_small && act && k < P.topo) P.nei[((size_t)e * n_a + i) * P.topo + k] = used ? nj[k] : -1;
         }
         snei[at * kNeiStride + kTopoMax] = (short)(collision ? 1 : 0);
     }
@@ -927,10 +917,13 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     part_c[sx * AG + at] = bc;
+    asm volatile("" :: "v"(warm));       // keeps the warming loads of the prologue alive; long retired by now
+    STAMP(16);
     EXIT_AT(4);
     __syncthreads();
+    STAMP(17);
     // merge the splits' candidates exactly: (d2 in fp64, cell index) lexicographic minimum = first minimum
-    double best = INFINITY; bc = 0;
+    double best = INFINITY, bex = 0.0, bey = 0.0; bc = 0;             // (bex, bey) = nearest cell - own position
     for (int rep = 0, reps = REPS(12); rep < reps; ++rep) {
     FENCE();
     best = INFINITY; bc = 0;
@@ -940,16 +933,48 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const double2 g = cell64(c);
         const double ex = g.x - px, ey = g.y - py;
         const double d = ex * ex + ey * ey;
-        if (d < best || (d == best && c < bc)) { best = d; bc = c; }
+        if (d < best || (d == best && c < bc)) { best = d; bc = c; bex = ex; bey = ey; }
     }
     }
     const bool in_shape = act && best < P.c_in[es];                    // CPP:889
     if (sx == 0) {
         sncf[at] = bc | (in_shape ? (1 << 30) : 0);
-        if (act) {
+        if (P.export_small && act) {
             P.near_cell[(size_t)e * n_a + i] = bc;
             P.in_flag[(size_t)e * n_a + i] = in_shape ? 1 : 0;
         }
+    }
+    // ---- prior policy, calculateActionPrior / robotPolicy CPP:1061-1196: a function of the positions, velocities,
+    // neighbour list and nearest cell of THIS observation -- exactly what the reference feeds it at the start of the
+    // next step (ENV:605-624: pre-integration state, previous neighbor_index).  It is evaluated here, where the neighbour
+    // list (LDS) and the nearest cell are at hand, and left in HBM for the next launch.  Its seven terms (attraction +
+    // one repulsion term per neighbour) are each a dependent fp64 sqrt / division chain: they are dealt over the splits
+    // and parked in LDS (the list region, unused until the emission); split B adds them up in the reference's order
+    // after the next barrier.
+    double *ptk = reinterpret_cast<double *>(smem + P.off_sidx);        // [14][AG]: (x, y) of neighbour terms 0..5, attraction
+    if (P.with_prior) {
+        unsigned fl = 0;
+#pragma unroll
+        for (int k = 0; k < kTopoMax; ++k) {
+            if ((k % WPE) != sx) continue;
+            const int j = snei[at * kNeiStride + k];
+            const bool used = j >= 0;
+            const int tj = el * NPAD + (used ? j : 0);
+            const double x = px - sp[tj], y = py - sp[AG + tj];
+            const double d = sqrt(x * x + y * y);
+            const double ux = x / d, uy = y / d;
+            const double factor = 3.0 * (P.r_avoid / d - 1.0);
+            ptk[(2 * k) * AG + at] = factor * ux; ptk[(2 * k + 1) * AG + at] = factor * uy;
+            if (used && d > 0 && d < P.r_avoid) fl |= 1u << (8 + k);
+        }
+        if (sx == (kTopoMax % WPE)) {
+            // target: own position when in shape (CPP:889-897) => zero attraction; else the nearest cell
+            const double tx = in_shape ? px - px : bex, ty = in_shape ? py - py : bey;
+            const double dt_ = sqrt(tx * tx + ty * ty);
+            ptk[12 * AG + at] = 2.0 * tx / dt_; ptk[13 * AG + at] = 2.0 * ty / dt_;
+            if (dt_ > 0) fl |= 1u << 14;
+        }
+        if (fl != 0) atomicOr(&sflag[at], (int)fl);
     }
     STAMP(4);
     EXIT_AT(5);
@@ -973,7 +998,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 const unsigned cw_ = cov[el * (P.ngw + 1) + w];
                 if (in_shape) {
                     kw = word & ~cw_;
-                    if (sflag[at] != 0) {
+                    if ((sflag[at] & 1) != 0) {
                         unsigned it = word & cw_;
                         kw = word;
                         while (it) {
@@ -1020,6 +1045,30 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     __syncthreads();
+    if (sx == SB && P.with_prior) {
+        // the prior's terms in the reference's order of additions (CPP:1136-1190): attraction, repulsion per neighbour in
+        // list order, alignment with the mean neighbour velocity
+        const unsigned fl = (unsigned)sflag[at];
+        double qx = 0.0, qy = 0.0;
+        if (fl & (1u << 14)) { qx += ptk[12 * AG + at]; qy += ptk[13 * AG + at]; }
+        double avx = 0.0, avy = 0.0; int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kTopoMax; ++k) {
+            const int j = snei[at * kNeiStride + k];
+            const bool used = j >= 0;
+            const int tj = el * NPAD + (used ? j : 0);
+            if (fl & (1u << (8 + k))) { qx += ptk[(2 * k) * AG + at]; qy += ptk[(2 * k + 1) * AG + at]; }
+            if (used) { avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt; }
+        }
+        if (cnt > 0) {
+            avx /= cnt; avy /= cnt;
+            qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
+        }
+        if (act) {
+            OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
+            reinterpret_cast<OT2 *>(P.prior_next)[(size_t)e * n_a + i] = o;
+        }
+    }
     STAMP(5);
     EXIT_AT(6);
 
@@ -1092,6 +1141,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     __syncthreads();
+    STAMP(18);
     EXIT_AT(7);
     // (2) emit: the kept list of an agent is cut into WPE contiguous RANK ranges, one per split.  Each lane walks its
     // own range bit by bit with a lane-private word pointer, so a wave's trip count is the longest range of any lane
@@ -1151,7 +1201,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
     }
+    STAMP(19);
     __syncthreads();
+    STAMP(20);
     EXIT_AT(8);
     // exploration-reward sums over the capped list (CPP:494-551), fp32 fast path: split sx takes slots
     // sx, sx+WPE, ...; independent iterations (unrolled).  The fp32 result only DECIDES when |v| is outside a
@@ -1192,6 +1244,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         rsum[(sx * 3 + 0) * AG + at] = num0; rsum[(sx * 3 + 1) * AG + at] = num1; rsum[(sx * 3 + 2) * AG + at] = den;
     }
+    STAMP(21);
     __syncthreads();
     STAMP(6);
     EXIT_AT(9);
@@ -1259,8 +1312,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         }
         if (act) {
-            if (reward != nullptr) reward[(size_t)e * n_a + i] = (in_shape && !(snei[at * kNeiStride + kTopoMax] != 0) && uniform) ? 1.0f : 0.0f;   // CPP:554-556
-            if (done != nullptr) done[(size_t)e * n_a + i] = 0;                                                         // ENV:480-482
+            if (reward != nullptr) __builtin_nontemporal_store((in_shape && !(snei[at * kNeiStride + kTopoMax] != 0) && uniform) ? 1.0f : 0.0f, &reward[(size_t)e * n_a + i]);   // CPP:554-556
+            if (done != nullptr) __builtin_nontemporal_store((uint8_t)0, &done[(size_t)e * n_a + i]);                                                         // ENV:480-482
         }
         if (P.export_idx && act) {
             const short *row = sidx + (size_t)at * P.g_stride;
@@ -1287,6 +1340,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             for (; os < O; ++os) eo[os] = -1;
         }
     }
+    STAMP(22);
     EXIT_AT(10);
 
     // ---- observation rows, CPP:102-137,274-306, streamed out as (value, value) pairs with consecutive lanes
@@ -1329,7 +1383,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 double a = ma - sa_, b = mb - sb_;
                 if (P.periodic && is_nei && half == 0) wrap_rel(a, b, P.w_half, P.h_half);      // CPP:79 relative position, wrapped
                 OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
-                out[(size_t)r * PPR + q] = o;
+                store_nt(&out[(size_t)r * PPR + q], o);
             };
             if (T % HP == 0) {
                 // the usual case (HP = 16): a thread keeps its pair index q for all its rows, so the kind of pair it
@@ -1350,6 +1404,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 }
             }
         }
+        STAMP(9);
         EXIT_AT(11);
         for (int rep = 0, reps = REPS(8); rep < reps; ++rep) {
             FENCE();
@@ -1371,7 +1426,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     double a = 0.0, b = 0.0;
                     if (c >= 0) { const double2 g = gr[c]; a = g.x - qx; b = g.y - qy; }
                     OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
-                    orow[q] = o;
+                    store_nt(&orow[q], o);
                 }
             }
             if (tail) {                                   // the last (G mod 64) slots: several rows per wave pass
@@ -1389,7 +1444,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         double a = 0.0, b = 0.0;
                         if (c >= 0) { const double2 g = gr[c]; a = g.x - sp[tr]; b = g.y - sp[AG + tr]; }
                         OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
-                        out[(size_t)r * PPR + HP + q] = o;
+                        store_nt(&out[(size_t)r * PPR + HP + q], o);
                     }
                 }
             }
@@ -1397,8 +1452,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     STAMP(7);
 #ifdef SWARM_STAMPS
-    if (P.stamps != nullptr && tid == 0)
-        for (int k = 0; k < 16; ++k) P.stamps[(size_t)blockIdx.x * 16 + k] = stamp_t[k];
+    if (P.stamps != nullptr && lane == 0) P.stamps[((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 24 + 23] = sx;   // slot 23 = the wave's split (role)
 #endif
 }
 
@@ -1731,6 +1785,7 @@ struct swarm_env {
     bool lattice_disabled;
     int *d_nei, *d_near, *d_inflag, *d_ng, *d_exp_sensed, *d_exp_occ;
     unsigned long long *d_hit;
+    void *d_prior;
 };
 
 namespace {
@@ -1849,7 +1904,7 @@ void layout_t(KP &k)
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4 + (NW > 1 ? NW * 1536 : 0)), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
-    k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, (size_t)(NW == 1 ? WPE * 4 : 5) * NW * AG * 8));  // sidx | pm (per-split copies for N <= 64, one accumulator set above)
+    k.off_sidx = take(max2(max2((size_t)AG * k.g_stride * 2, (size_t)(NW == 1 ? WPE * 4 : 5) * NW * AG * 8), (size_t)14 * AG * 8));  // sidx | pm (per-split copies for N <= 64, one accumulator set above)
     k.off_partc = take((size_t)WPE * AG * 4);
     k.off_lat = take((size_t)EPB * 64 * (8 + 2));
     k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
@@ -1982,7 +2037,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->lat_R.assign((size_t)cfg->n_env, 0.0f); h->lat_Rc.assign((size_t)cfg->n_env, 0.0f);
     h->lat_ncols.assign((size_t)cfg->n_env, 0);
     h->lattice_disabled = (cfg->debug_flags & 2) != 0;
-    h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr; h->d_hit = nullptr;
+    h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr; h->d_hit = nullptr; h->d_prior = nullptr;
     h->cells_set.assign((size_t)cfg->n_env, 0);
     h->npad = npad_for(cfg->n_agents);
 
@@ -2060,10 +2115,12 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     alloc((void **)&h->d_cells, E * 2 * (size_t)k.ng_max * 8); alloc((void **)&h->d_cin, E * 8);
     alloc((void **)&h->d_cells_xy, E * (size_t)k.ng_max * 16);
     alloc((void **)&h->d_ng, E * 4); alloc((void **)&h->d_shape_idx, E * 4);
+    alloc((void **)&h->d_prior, E * N * 16);
     alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
     alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_hit, E * N * 8 * (size_t)std::max(1, h->npad / 64));
     if (a == hipSuccess) a = hipMemset(h->d_ng, 0, E * 4);
+    if (a == hipSuccess) a = hipMemset(h->d_prior, 0, E * N * 16);
     if (a == hipSuccess) a = hipMemset(h->d_shape_idx, 0xFF, E * 4);
     if (a == hipSuccess) a = hipMemset(h->d_nei, 0xFF, E * N * (size_t)k.topo * 4);
     if (a == hipSuccess) a = hipMemset(h->d_near, 0, E * N * 4);
@@ -2079,6 +2136,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
         return fail(nullptr, SWARM_ERR_HIP, m);
     }
     k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag; k.hit = h->d_hit;
+    k.prior_next = h->d_prior;
     k.cells = h->d_cells; k.cells_xy = h->d_cells_xy; k.n_g = h->d_ng; k.c_in = h->d_cin;
     k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_nrs = k.lat_nrc = 0; k.lat_n32 = 0;
     k.c_near_hi = k.c_near * (1.0 + 1e-9);
@@ -2094,7 +2152,7 @@ int swarm_destroy(swarm_env_t *h)
         (void)hipStreamSynchronize(h->stream);
         (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin); (void)hipFree(h->d_cells_xy);
         (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag); (void)hipFree(h->d_hit);
-        (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat); (void)hipFree(h->d_shape_idx);
+        (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat); (void)hipFree(h->d_shape_idx); (void)hipFree(h->d_prior);
         (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -2335,16 +2393,19 @@ int swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flags
     if (!h->observed) return fail(h, SWARM_ERR_STATE, "swarm_get_indices: nothing observed yet");
     DeviceGuard g(h->device);
     const size_t EN = (size_t)h->cfg.n_env * h->cfg.n_agents;
-    if (sensed_index || occupied_index) {
-        if (!h->d_exp_sensed) {
-            HIP_TRY(h, hipMalloc((void **)&h->d_exp_sensed, EN * (size_t)h->kp.g_max * 4));
-            HIP_TRY(h, hipMalloc((void **)&h->d_exp_occ, EN * (size_t)h->kp.occ_max * 4));
-        }
-        // re-run the observation pass on the current state with the export switched on; it recomputes the
-        // same caches from the same state, so it is idempotent.
-        h->kp.export_idx = 1; h->kp.exp_sensed = h->d_exp_sensed; h->kp.exp_occ = h->d_exp_occ;
+    const bool lists = sensed_index || occupied_index;
+    if (lists && !h->d_exp_sensed) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_exp_sensed, EN * (size_t)h->kp.g_max * 4));
+        HIP_TRY(h, hipMalloc((void **)&h->d_exp_occ, EN * (size_t)h->kp.occ_max * 4));
+    }
+    {
+        // re-run the observation pass on the current state with the export switched on (the step keeps the index
+        // scratch in LDS and writes none of it to HBM); it recomputes the same caches from the same state, so it is
+        // idempotent.
+        h->kp.export_small = 1;
+        if (lists) { h->kp.export_idx = 1; h->kp.exp_sensed = h->d_exp_sensed; h->kp.exp_occ = h->d_exp_occ; }
         int rc = launch(h, false, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
-        h->kp.export_idx = 0;
+        h->kp.export_idx = 0; h->kp.export_small = 0;
         if (rc != SWARM_OK) return rc;
         if (sensed_index) HIP_TRY(h, hipMemcpyAsync(sensed_index, h->d_exp_sensed, EN * (size_t)h->kp.g_max * 4, hipMemcpyDefault, h->stream));
         if (occupied_index) HIP_TRY(h, hipMemcpyAsync(occupied_index, h->d_exp_occ, EN * (size_t)h->kp.occ_max * 4, hipMemcpyDefault, h->stream));
@@ -2367,9 +2428,9 @@ int swarm_rule_action(swarm_env_t *h, double *action)
         HIP_TRY(h, hipMalloc((void **)&h->d_exp_occ, EN * (size_t)h->kp.occ_max * 4));
     }
     // observation pass on the current state with the index export switched on (idempotent, see swarm_get_indices)
-    h->kp.export_idx = 1; h->kp.exp_sensed = h->d_exp_sensed; h->kp.exp_occ = h->d_exp_occ;
+    h->kp.export_idx = 1; h->kp.export_small = 1; h->kp.exp_sensed = h->d_exp_sensed; h->kp.exp_occ = h->d_exp_occ;
     int rc = launch(h, false, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
-    h->kp.export_idx = 0;
+    h->kp.export_idx = 0; h->kp.export_small = 0;
     if (rc != SWARM_OK) return rc;
     hipLaunchKernelGGL(k_rule, dim3(h->cfg.n_env), dim3(h->cfg.n_agents <= 64 ? 64 : 256), 0, h->stream, h->kp, action);
     HIP_TRY(h, hipGetLastError());
@@ -2414,7 +2475,7 @@ int swarm_timer_stop(swarm_env_t *h, float *ms)
 
 
 #ifdef SWARM_STAMPS
-// Diagnostic build only: run one step with per-block phase clocks; out[grid][8] (host), returns grid size.
+// Diagnostic build only: run one step with per-wave phase clocks; out[grid][waves per workgroup][24] (host), returns grid size.
 int swarm_debug_stamps(swarm_env_t *h, const void *action, int action_dtype, void *obs, float *reward, uint8_t *done,
                        void *a_prior, long long *out, int max_blocks)
 {
@@ -2422,13 +2483,15 @@ int swarm_debug_stamps(swarm_env_t *h, const void *action, int action_dtype, voi
     DeviceGuard g(h->device);
     const int epb = h->npad < 64 ? 64 / h->npad : 1;
     const int grid = (h->cfg.n_env + epb - 1) / epb;   // same for every Geo<NPAD>
+    const int wpb = (h->npad < 64 ? 64 : h->npad) * 4 / 64;      // waves per workgroup
     if (grid > max_blocks) return -1;
     long long *d = nullptr;
-    if (hipMalloc((void **)&d, (size_t)grid * 16 * sizeof(long long)) != hipSuccess) return -1;
+    if (hipMalloc((void **)&d, (size_t)grid * wpb * 24 * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, (size_t)grid * wpb * 24 * sizeof(long long));
     h->kp.stamps = d;
     int rc = launch(h, true, action, action_dtype == SWARM_F64, obs, reward, done, a_prior);
     h->kp.stamps = nullptr;
-    if (rc == SWARM_OK && hipMemcpy(out, d, (size_t)grid * 16 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+    if (rc == SWARM_OK && hipMemcpy(out, d, (size_t)grid * wpb * 24 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
     (void)hipFree(d);
     return rc == SWARM_OK ? grid : -1;
 }

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: where does one env-step kernel spend its cycles?  Builds/loads the -DSWARM_STAMPS library
-(in-kernel clock64 stamps at phase boundaries, wave 0 of every workgroup) and prints the share of each phase.
-Read SHARES, not absolute time: the stamps fence the scheduler (see cdna_hip_programming.md section 7).  The stamped wave's
-role rotates with the workgroup index, so the shares are an average over the four roles; tools/ablate.py --cumulative is
-the better instrument for throughput."""
+"""Diagnostic: where does one env-step kernel spend its cycles, per wave ROLE?  Loads the -DSWARM_STAMPS library
+(marl_llm_amd.build.build_lib(stamps=True): in-kernel clock64 stamps at every barrier and phase boundary, one record per
+wave) and prints, for each role (split A = forces / reward combine, B = prior / insertion, C and D = walk only), the mean
+cycles between consecutive stamp points.  Read SHARES, not absolute time: the stamps fence the scheduler
+(cdna_hip_programming.md section 7).  Usage: python3 tools/phase_profile.py [agents] [envs]"""
 import ctypes
 import os
 import sys
@@ -19,8 +19,13 @@ from marl_llm_amd.batched import SwarmBatch
 from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
 from marl_llm_amd.synth import synthetic_batch
 
-PHASES = ["load cells+state", "forces+prior+integrate", "neighbour search", "cell scan", "occupied filter",
-          "sensed list+reward", "obs stream"]
+# stamp ids in program order and what ENDS at each of them
+ORDER = [(0, "start"), (1, "prologue loads + barrier"), (2, "forces | prior, integrate, 2 barriers"),
+         (14, "pair-mask loop"), (15, "pair masks: LDS exchange + barrier"), (3, "ordered insertion (B only)"),
+         (16, "lattice walk (not B)"), (17, "barrier after walk"), (4, "nearest merge (gathers)"),
+         (5, "occupied filter + barrier"), (18, "rank-select + barrier"), (19, "list emission"),
+         (20, "barrier after emission"), (21, "reward sums (gathers)"), (6, "barrier after reward sums"),
+         (22, "reward combine + stores (A only)"), (9, "obs head pairs"), (7, "obs sensed pairs")]
 
 
 def main():
@@ -37,20 +42,38 @@ def main():
     fn = sb.lib.swarm_debug_stamps
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int]
-    grid_max = E
-    out = np.zeros((grid_max, 16), np.int64)
+    npad = max(8, 1 << (n_a - 1).bit_length())
+    wpb = max(64, npad) * 4 // 64
+    epb = 64 // npad if npad < 64 else 1
+    grid = (E + epb - 1) // epb
+    out = np.zeros((grid, wpb, 24), np.int64)
     obs, rew, done, pri = sb._obs[0], sb._rew[0], sb._done, sb._pri[0]
     g = fn(sb.handle, act.data_ptr(), 0, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), pri.data_ptr(),
-           out.ctypes.data_as(ctypes.c_void_p), grid_max)
-    assert g > 0, g
-    t = out[:g].astype(np.float64)
-    t = t[:, :8]
-    d = np.diff(t, axis=1)
-    tot = t[:, 7] - t[:, 0]
-    print(f"{n_a} agents x {E} envs: {g} workgroups, mean cycles/workgroup {tot.mean():.0f} "
-          f"(min {tot.min():.0f}, max {tot.max():.0f}); kernel span {(t[:, 7].max() - t[:, 0].min()):.0f} cycles")
-    for k, name in enumerate(PHASES):
-        print(f"  {name:26s} {d[:, k].mean():10.0f} cycles  {100 * d[:, k].mean() / tot.mean():5.1f} %")
+           out.ctypes.data_as(ctypes.c_void_p), grid)
+    assert g == grid, g
+    t = out.reshape(-1, 24).astype(np.float64)
+    role = out.reshape(-1, 24)[:, 23]
+    span = t[:, 7].max() - t[:, 0].min()
+    life = t[:, 7] - t[:, 0]
+    print(f"{n_a} agents x {E} envs: {grid} workgroups x {wpb} waves; kernel span {span:.0f} cycles; "
+          f"mean wave life {life.mean():.0f} cycles (min {life.min():.0f}, max {life.max():.0f})")
+    names = {0: "A (forces, reward combine)", 1: "B (prior, insertion)", 2: "C (walk)", 3: "D (walk)"}
+    ids = [k for k, _ in ORDER]
+    print(f"{'segment':44s}" + "".join(f"{names[r][:1]:>10s}" for r in range(4)) + "      all   share")
+    tot_all = life.mean()
+    for q in range(1, len(ORDER)):
+        k, nm = ORDER[q]
+        cols = []
+        for r in range(4):
+            m = role == r
+            # a stamp a role never reaches (value 0) inherits the previous one: carry forward
+            cur = t[m][:, ids[: q + 1]].copy()
+            for c in range(1, cur.shape[1]):
+                z = cur[:, c] == 0
+                cur[z, c] = cur[z, c - 1]
+            cols.append((cur[:, q] - cur[:, q - 1]).mean())
+        allm = float(np.mean(cols))
+        print(f"{nm:44s}" + "".join(f"{c:10.0f}" for c in cols) + f"{allm:9.0f}  {100 * allm / tot_all:5.1f} %")
 
 
 if __name__ == "__main__":
