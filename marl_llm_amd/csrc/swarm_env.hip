@@ -962,17 +962,18 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const int tj = el * NPAD + (used ? j : 0);
             const double x = px - sp[tj], y = py - sp[AG + tj];
             const double d = sqrt(x * x + y * y);
-            const double ux = x / d, uy = y / d;
-            const double factor = 3.0 * (P.r_avoid / d - 1.0);
-            ptk[(2 * k) * AG + at] = factor * ux; ptk[(2 * k + 1) * AG + at] = factor * uy;
-            if (used && d > 0 && d < P.r_avoid) fl |= 1u << (8 + k);
+            if (used && d > 0 && d < P.r_avoid) {                   // the (rare) close neighbours only: three fp64 divisions
+                const double ux = x / d, uy = y / d;
+                const double factor = 3.0 * (P.r_avoid / d - 1.0);
+                ptk[(2 * k) * AG + at] = factor * ux; ptk[(2 * k + 1) * AG + at] = factor * uy;
+                fl |= 1u << (8 + k);
+            }
         }
         if (sx == (kTopoMax % WPE)) {
             // target: own position when in shape (CPP:889-897) => zero attraction; else the nearest cell
             const double tx = in_shape ? px - px : bex, ty = in_shape ? py - py : bey;
             const double dt_ = sqrt(tx * tx + ty * ty);
-            ptk[12 * AG + at] = 2.0 * tx / dt_; ptk[13 * AG + at] = 2.0 * ty / dt_;
-            if (dt_ > 0) fl |= 1u << 14;
+            if (dt_ > 0) { ptk[12 * AG + at] = 2.0 * tx / dt_; ptk[13 * AG + at] = 2.0 * ty / dt_; fl |= 1u << 14; }
         }
         if (fl != 0) atomicOr(&sflag[at], (int)fl);
     }
@@ -1412,6 +1413,34 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             // and each store instruction covers 64 consecutive pairs (512 B / 1 KiB contiguous).  CPP:274-291
             const int Gp = P.g_max;
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
+            if (Gp == 80 && sizeof(OT) <= 4) {
+                // the reference's list length: TWO slots per lane, so every store instruction writes 64 x 16 B (f32) of
+                // consecutive addresses -- half the store instructions of the pair-per-lane form, and the store path, not
+                // the arithmetic, bounds this phase.  A row has 40 two-slot chunks; 8 rows = 320 chunks = 5 full passes.
+                typedef OT OT4 __attribute__((ext_vector_type(4)));
+                for (int r0 = wv * 8; r0 < rows; r0 += nwv * 8) {
+#pragma unroll
+                    for (int ps = 0; ps < 5; ++ps) {
+                        const int ch = ps * 64 + lane;                   // 0..319
+                        const int rl = (ch * 205) >> 13;                 // ch / 40 (exact for ch < 320)
+                        const int m = ch - rl * 40;
+                        const int r = r0 + rl;
+                        if (r < rows) {
+                            const int elr = EPB > 1 ? r / n_a : 0;
+                            const int tr = elr * NPAD + (r - elr * n_a);
+                            const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
+                            const double qx = sp[tr], qy = sp[AG + tr];
+                            const int cc = *reinterpret_cast<const int *>(sidx + (size_t)tr * P.g_stride + 2 * m);
+                            const int c0 = (int)(short)(cc & 0xFFFF), c1 = cc >> 16;
+                            double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+                            if (c0 >= 0) { const double2 g = gr[c0]; a0 = g.x - qx; b0 = g.y - qy; }
+                            if (c1 >= 0) { const double2 g = gr[c1]; a1 = g.x - qx; b1 = g.y - qy; }
+                            OT4 o = {to_out<OT>(a0), to_out<OT>(b0), to_out<OT>(a1), to_out<OT>(b1)};
+                            __builtin_nontemporal_store(o, reinterpret_cast<OT4 *>(out + (size_t)r * PPR + HP + 2 * m));
+                        }
+                    }
+                }
+            } else {
             const int nfull = Gp >> 6, tail = Gp & 63;
             for (int r = wv; r < rows; r += nwv) {
                 const int elr = EPB > 1 ? r / n_a : 0;
@@ -1447,6 +1476,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         store_nt(&out[(size_t)r * PPR + HP + q], o);
                     }
                 }
+            }
             }
         }
     }
