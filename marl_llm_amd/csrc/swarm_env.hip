@@ -69,7 +69,7 @@ struct KP {
     int cxy_stride;            // double2 elements per env in LDS
     int cxq_stride;            // floats per env in the fp32 pair layout
     int g_stride;              // int16 elements per agent row in LDS
-    int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear, off_pc;
+    int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear;
     int smem_lat, smem_lat_export, smem_generic;   // dynamic LDS bytes by launch kind
     double c_sen, c_near, c_occ, c_avoid, c_ball;     // squared-distance cut-offs
     double c_close, c_close2;  // (1.9 r_avoid)^2 and (3 r_avoid)^2 capped at c_sen: pre-selection radii of the neighbour insertion (any values are exact; the second is used for N > 128)
@@ -267,7 +267,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     short *snei = reinterpret_cast<short *>(smem + P.off_snei);          // [AG][kTopoMax]
     int *sncf = reinterpret_cast<int *>(smem + P.off_sncf);              // [AG]: nearest cell | in_flag<<30
     u64 *snear = reinterpret_cast<u64 *>(smem + P.off_snear);            // [NW][AG] nearby-agent masks
-    unsigned char *pc = smem + P.off_pc;                                 // [word][AG] kept-bit counts
     u64 *lrm = reinterpret_cast<u64 *>(smem + P.off_lat);                // [EPB][64] lattice row masks
     short *lrs = reinterpret_cast<short *>(smem + P.off_lat + (size_t)EPB * 64 * 8);   // [EPB][64] row starts
     unsigned *cov = reinterpret_cast<unsigned *>(smem + P.off_cov);      // [EPB][ngw+1] cells within r_avoid/2 of ANY agent
@@ -944,132 +943,90 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             P.in_flag[(size_t)e * n_a + i] = in_shape ? 1 : 0;
         }
     }
-    // ---- prior policy, calculateActionPrior / robotPolicy CPP:1061-1196: a function of the positions, velocities,
-    // neighbour list and nearest cell of THIS observation -- exactly what the reference feeds it at the start of the
-    // next step (ENV:605-624: pre-integration state, previous neighbor_index).  It is evaluated here, where the neighbour
-    // list (LDS) and the nearest cell are at hand, and left in HBM for the next launch.  Its seven terms (attraction +
-    // one repulsion term per neighbour) are each a dependent fp64 sqrt / division chain: they are dealt over the splits
-    // and parked in LDS (the list region, unused until the emission); split B adds them up in the reference's order
-    // after the next barrier.
-    double *ptk = reinterpret_cast<double *>(smem + P.off_sidx);        // [14][AG]: (x, y) of neighbour terms 0..5, attraction
-    if (P.with_prior) {
-        unsigned fl = 0;
-#pragma unroll
-        for (int k = 0; k < kTopoMax; ++k) {
-            if ((k % WPE) != sx) continue;
-            const int j = snei[at * kNeiStride + k];
-            const bool used = j >= 0;
-            const int tj = el * NPAD + (used ? j : 0);
-            const double x = px - sp[tj], y = py - sp[AG + tj];
-            const double d = sqrt(x * x + y * y);
-            if (used && d > 0 && d < P.r_avoid) {                   // the (rare) close neighbours only: three fp64 divisions
-                const double ux = x / d, uy = y / d;
-                const double factor = 3.0 * (P.r_avoid / d - 1.0);
-                ptk[(2 * k) * AG + at] = factor * ux; ptk[(2 * k + 1) * AG + at] = factor * uy;
-                fl |= 1u << (8 + k);
-            }
-        }
-        if (sx == (kTopoMax % WPE)) {
-            // target: own position when in shape (CPP:889-897) => zero attraction; else the nearest cell
-            const double tx = in_shape ? px - px : bex, ty = in_shape ? py - py : bey;
-            const double dt_ = sqrt(tx * tx + ty * ty);
-            if (dt_ > 0) { ptk[12 * AG + at] = 2.0 * tx / dt_; ptk[13 * AG + at] = 2.0 * ty / dt_; fl |= 1u << 14; }
-        }
-        if (fl != 0) atomicOr(&sflag[at], (int)fl);
-    }
     STAMP(4);
     EXIT_AT(5);
 
     // ---- occupied-cell filter, CPP:144-216: a sensed cell is occupied iff some nearby agent is within
-    // r_avoid/2 of it; only agents inside the shape filter (CPP:150).
-    {
-        u64 nearby[NW];
-#pragma unroll
-        for (int q = 0; q < NW; ++q) nearby[q] = (NW > 1 && in_shape) ? snear[q * AG + at] : 0;
-        for (int rep = 0, reps = REPS(4); rep < reps; ++rep)
-        for (int w = 0; w < W; ++w) {
-            if (!mine(w)) continue;
-            FENCE();
-            const unsigned word = sbits[w * AG + at];
-            unsigned kw = word;
-            if (use_lat) {
-                // occupied <=> within r_avoid/2 of ANY agent: the covering agent of a SENSED cell is "nearby"
-                // (CPP:161) by the triangle inequality, except when its distance sits within rounding of the
-                // nearby threshold -- those lanes were flagged by the pair pass and are resolved exactly.
-                const unsigned cw_ = cov[el * (P.ngw + 1) + w];
-                if (in_shape) {
-                    kw = word & ~cw_;
-                    if ((sflag[at] & 1) != 0) {
-                        unsigned it = word & cw_;
-                        kw = word;
-                        while (it) {
-                            const int b = __ffs(it) - 1; it &= it - 1;
-                            const double2 g = cell64(w * 32 + b);
-                            bool occ = false;
-                            for (int q = 0; q < NW && !occ; ++q) {
-                                u64 nbm = NW == 1 ? (nearby1 >> (NPAD < 64 ? el * NPAD : 0)) : snear[q * AG + at];
-                                while (nbm && !occ) {
-                                    const int j = q * 64 + __ffsll((unsigned long long)nbm) - 1; nbm &= nbm - 1;
-                                    const double ex = g.x - spx[j], ey = g.y - spy[j];
-                                    occ = ex * ex + ey * ey < P.c_occ;
+    // r_avoid/2 of it; only agents inside the shape filter (CPP:150).  kept = in_shape ? sensed & ~occupied : sensed.
+    // Common case (N <= 64, no index export, no agent flagged by the pair pass): the occupied bits of every word are
+    // already in LDS -- the env's covered-cell set (lattice walk) or the scan's per-agent words -- so nothing is
+    // rewritten and no barrier is needed: the readers below AND the two words on the fly.  Otherwise (N > 64: per-cell
+    // ballots; generic cell sets: the occupied words share LDS with the rank-select bits; export: the occupied bits
+    // themselves are wanted; a flagged agent: exact per-cell test) the words of the sensed set are filtered in place, dealt
+    // over the splits, behind a barrier.
+    const bool flagged = use_lat && __any((sflag[at] & 1) != 0) != 0;
+    const bool slow_filter = NW > 1 || !use_lat || P.export_idx != 0 || flagged;     // workgroup-uniform for N <= 64: every wave holds the same agents
+    if (slow_filter) {
+        {
+            u64 nearby[NW];
+    #pragma unroll
+            for (int q = 0; q < NW; ++q) nearby[q] = (NW > 1 && in_shape) ? snear[q * AG + at] : 0;
+            for (int rep = 0, reps = REPS(4); rep < reps; ++rep)
+            for (int w = 0; w < W; ++w) {
+                if (!mine(w)) continue;
+                FENCE();
+                const unsigned word = sbits[w * AG + at];
+                unsigned kw = word;
+                if (use_lat) {
+                    // occupied <=> within r_avoid/2 of ANY agent: the covering agent of a SENSED cell is "nearby"
+                    // (CPP:161) by the triangle inequality, except when its distance sits within rounding of the
+                    // nearby threshold -- those lanes were flagged by the pair pass and are resolved exactly.
+                    const unsigned cw_ = cov[el * (P.ngw + 1) + w];
+                    if (in_shape) {
+                        kw = word & ~cw_;
+                        if ((sflag[at] & 1) != 0) {
+                            unsigned it = word & cw_;
+                            kw = word;
+                            while (it) {
+                                const int b = __ffs(it) - 1; it &= it - 1;
+                                const double2 g = cell64(w * 32 + b);
+                                bool occ = false;
+                                for (int q = 0; q < NW && !occ; ++q) {
+                                    u64 nbm = NW == 1 ? (nearby1 >> (NPAD < 64 ? el * NPAD : 0)) : snear[q * AG + at];
+                                    while (nbm && !occ) {
+                                        const int j = q * 64 + __ffsll((unsigned long long)nbm) - 1; nbm &= nbm - 1;
+                                        const double ex = g.x - spx[j], ey = g.y - spy[j];
+                                        occ = ex * ex + ey * ey < P.c_occ;
+                                    }
                                 }
+                                if (occ) kw &= ~(1u << b);
                             }
-                            if (occ) kw &= ~(1u << b);
                         }
                     }
-                }
-                if (rep == reps - 1) sbits[w * AG + at] = kw;
-            } else if constexpr (NW == 1) {
-                if (in_shape) kw = word & ~owords[w * AG + at];       // occupied bits came out of the scan
-                if (rep == reps - 1) sbits[w * AG + at] = kw;
-            } else if (in_shape) {
-                unsigned it = word;
-                while (it) {
-                    int bb[4]; bool occ[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { bb[u] = it ? __ffs(it) - 1 : -1; it &= it - 1; }   // it - 1 of 0 is harmless: it stays 0
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int c = w * 32 + (bb[u] < 0 ? 0 : bb[u]);
-                        occ[u] = false;
-#pragma unroll
-                        for (int q = 0; q < NW; ++q) occ[u] = occ[u] || ((cmask[(size_t)c * NW + q] & nearby[q]) != 0);
+                    if (rep == reps - 1) sbits[w * AG + at] = kw;
+                } else if constexpr (NW == 1) {
+                    if (in_shape) kw = word & ~owords[w * AG + at];       // occupied bits came out of the scan
+                    if (rep == reps - 1) sbits[w * AG + at] = kw;
+                } else if (in_shape) {
+                    unsigned it = word;
+                    while (it) {
+                        int bb[4]; bool occ[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) { bb[u] = it ? __ffs(it) - 1 : -1; it &= it - 1; }   // it - 1 of 0 is harmless: it stays 0
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = w * 32 + (bb[u] < 0 ? 0 : bb[u]);
+                            occ[u] = false;
+    #pragma unroll
+                            for (int q = 0; q < NW; ++q) occ[u] = occ[u] || ((cmask[(size_t)c * NW + q] & nearby[q]) != 0);
+                        }
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) if (bb[u] >= 0 && occ[u]) kw &= ~(1u << bb[u]);
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) if (bb[u] >= 0 && occ[u]) kw &= ~(1u << bb[u]);
+                    if (rep == reps - 1) sbits[w * AG + at] = kw;
                 }
-                if (rep == reps - 1) sbits[w * AG + at] = kw;
+                asm volatile("" :: "v"(kw));
+                if (P.export_idx) obits[w * AG + at] = word & ~kw;
             }
-            asm volatile("" :: "v"(kw));
-            if (P.export_idx) obits[w * AG + at] = word & ~kw;
-            pc[w * AG + at] = (unsigned char)__popc(kw);
         }
+
+        __syncthreads();
     }
-    __syncthreads();
-    if (sx == SB && P.with_prior) {
-        // the prior's terms in the reference's order of additions (CPP:1136-1190): attraction, repulsion per neighbour in
-        // list order, alignment with the mean neighbour velocity
-        const unsigned fl = (unsigned)sflag[at];
-        double qx = 0.0, qy = 0.0;
-        if (fl & (1u << 14)) { qx += ptk[12 * AG + at]; qy += ptk[13 * AG + at]; }
-        double avx = 0.0, avy = 0.0; int cnt = 0;
-#pragma unroll
-        for (int k = 0; k < kTopoMax; ++k) {
-            const int j = snei[at * kNeiStride + k];
-            const bool used = j >= 0;
-            const int tj = el * NPAD + (used ? j : 0);
-            if (fl & (1u << (8 + k))) { qx += ptk[(2 * k) * AG + at]; qy += ptk[(2 * k + 1) * AG + at]; }
-            if (used) { avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt; }
-        }
-        if (cnt > 0) {
-            avx /= cnt; avy /= cnt;
-            qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
-        }
-        if (act) {
-            OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
-            reinterpret_cast<OT2 *>(P.prior_next)[(size_t)e * n_a + i] = o;
-        }
-    }
+    auto kept_word = [&](int w) -> unsigned {
+        const unsigned word = sbits[w * AG + at];
+        if (slow_filter || !in_shape) return word;
+        return word & ~cov[el * (P.ngw + 1) + w];
+    };
     STAMP(5);
     EXIT_AT(6);
 
@@ -1077,7 +1034,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // Each split emits the slots of its own words (rank = prefix of the kept-bit counts) and accumulates
     // partial sums; the sums are combined in split order below.
     int n_kept = 0;
-    for (int w = 0; w < W; ++w) n_kept += pc[w * AG + at];
+    for (int w = 0; w < W; ++w) n_kept += __popc(kept_word(w));
     const int G = P.g_max;
     const int n_sel = n_kept > G ? G : n_kept;
     // (1) which RANKS of the kept list survive the cap?  rank(s) = round(s * (n-1)/(G-1)), s = 0..G-1 (CPP:241-245),
@@ -1094,6 +1051,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // answer in all WPE splits, they hold the same agents -- ranks are slots and the rank-select bits are skipped.
     const bool any_sub = __any(n_kept > G) != 0;
     int *sub_base = part_c;                  // [WPE][AG] first slot of each split's rank range, capped agents only (part_c is consumed)
+    // (for N <= 64 `any_sub` is the same in every wave of the workgroup, so the barriers it guards are uniform)
+    if (NW == 1 && any_sub && !slow_filter) __syncthreads();      // every split is done reading part_c (nearest-cell merge)
     if (any_sub)
     for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
         FENCE();
@@ -1141,12 +1100,13 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         }
     }
-    __syncthreads();
+    if (NW > 1 || any_sub) __syncthreads();
     STAMP(18);
     EXIT_AT(7);
     // (2) emit: the kept list of an agent is cut into WPE contiguous RANK ranges, one per split.  Each lane walks its
     // own range bit by bit with a lane-private word pointer, so a wave's trip count is the longest range of any lane
     // (n_kept / WPE) -- not, as with words dealt over the splits, the sum over words of the fullest lane's count.
+    int slot_lo = 0, slot_hi = 0;            // the slots this split emitted: its share of the reward sums below
     {
         short *row = sidx + (size_t)at * P.g_stride;
         for (int rep = 0, reps = REPS(11); rep < reps; ++rep) {
@@ -1159,12 +1119,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         {
             int prefix = 0;
             for (int w = 0; w < W; ++w) {                              // ww = number of words whose running count is <= k0
-                prefix += pc[w * AG + at];
+                prefix += __popc(kept_word(w));
                 const bool le = prefix <= k0;
                 ww += le ? 1 : 0; within = le ? k0 - prefix : within;
             }
         }
-        unsigned it = k0 < k1 ? sbits[ww * AG + at] : 0u;
+        unsigned it = k0 < k1 ? kept_word(ww) : 0u;
         {   // drop the `within` lowest set bits: position of the within-th set bit by a binary search on popcounts
             int p = 0, left = within;
 #pragma unroll
@@ -1177,6 +1137,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         // uncapped agent: rank = slot; capped: the rank-select pass counted the selected ranks below each split's range
         int slot = (n_kept > G && sx > 0) ? sub_base[sx * AG + at] : (n_kept > G ? 0 : k0);
+        slot_lo = slot;
         // two instantiations of the walk: without a capped agent in the wave every kept bit is taken and no selection
         // word is carried
         auto walk_range = [&](auto capped) {
@@ -1185,7 +1146,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             unsigned rw = (CAP && k0 < k1) ? rsel[(k0 >> 5) * AG + at] : 0xFFFFFFFFu;      // selection bits of ranks 32 (k >> 5) ...
             while (__any(k < k1)) {
                 if (k < k1) {
-                    if (it == 0) { ++ww; it = sbits[ww * AG + at]; }   // next word (more kept bits exist: k < k1 <= n_kept)
+                    if (it == 0) { ++ww; it = kept_word(ww); }         // next word (more kept bits exist: k < k1 <= n_kept)
                     if (it != 0) {
                         const int b = __ffs(it) - 1;
                         it &= it - 1;
@@ -1199,30 +1160,29 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         };
         if (any_sub) walk_range(std::true_type{}); else walk_range(std::false_type{});
+        slot_hi = slot;
         }
         for (int q = n_sel + sx; q < G; q += WPE) row[q] = -1;
     }
     STAMP(19);
-    __syncthreads();
+    if (NW > 1 || any_sub) __syncthreads();      // the partial sums below overwrite the rank-select bits other splits may still read
     STAMP(20);
     EXIT_AT(8);
-    // exploration-reward sums over the capped list (CPP:494-551), fp32 fast path: split sx takes slots
-    // sx, sx+WPE, ...; independent iterations (unrolled).  The fp32 result only DECIDES when |v| is outside a
-    // guard band around the 0.05 threshold; inside it the sums are redone in fp64 below.
+    // exploration-reward sums over the capped list (CPP:494-551), fp32 fast path: every split sums the slots it has just
+    // emitted itself (its own LDS writes: no barrier in between), two per iteration in packed fp32.  The fp32 result
+    // only DECIDES when |v| is outside a guard band around the 0.05 threshold; inside it the sums are redone in fp64 below.
     {
         const float inv_dsen2 = (float)(1.0 / (P.d_sen * P.d_sen));
         float num0 = 0.0f, num1 = 0.0f, den = 0.0f;
         const short *row = sidx + (size_t)at * P.g_stride;
-        const int lim = in_shape ? n_sel : 0;
+        const int lim = in_shape ? slot_hi : slot_lo;
         for (int rep = 0, reps = REPS(6); rep < reps; ++rep) {
         FENCE();
-        // two slots per iteration in packed fp32 (v_pk_*_f32): slots q and q + WPE
         f2v n0v = {0.0f, 0.0f}, n1v = {0.0f, 0.0f}, dnv = {0.0f, 0.0f};
         const f2v pxx2 = {pxf, pxf}, pyy2 = {pyf, pyf}, inv2 = {inv_dsen2, inv_dsen2};
-#pragma unroll 2
-        for (int q = sx; q < G; q += 2 * WPE) {
-            const bool va = q < lim, vb = q + WPE < lim;
-            const int ca = va ? row[q] : 0, cb = vb ? row[q + WPE] : 0;       // cell 0 stands in for an empty slot (weight zeroed)
+        for (int q = slot_lo; __any(q < lim); q += 2) {
+            const bool va = q < lim, vb = q + 1 < lim;
+            const int ca = va ? row[q] : 0, cb = vb ? row[q + 1] : 0;         // cell 0 stands in for an empty slot (weight zeroed)
             f2v gx, gy;
             if (use_lat) { const double2 ga = gce[ca], gb = gce[cb]; gx = f2v{(float)ga.x, (float)gb.x}; gy = f2v{(float)ga.y, (float)gb.y}; }
             else {
@@ -1344,6 +1304,45 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     STAMP(22);
     EXIT_AT(10);
 
+    // ---- prior policy, calculateActionPrior / robotPolicy CPP:1061-1196: a function of the positions, velocities,
+    // neighbour list and nearest cell of THIS observation -- exactly what the reference feeds it at the start of the
+    // next step (ENV:605-624: pre-integration state, previous neighbor_index).  Split B evaluates it here, where all of
+    // that sits in LDS, and leaves it in HBM for the next launch; the other splits write its share of the head pairs.
+    if (sx == SB && P.with_prior) {
+        double qx = 0.0, qy = 0.0;
+        {
+            const int ncf = sncf[at];
+            // target: own position when in shape (CPP:889-897) => zero attraction; else the nearest cell
+            double tx = px - px, ty = py - py;
+            if (!(ncf >> 30)) { const double2 g = cell64(ncf & 0xFFFF); tx = g.x - px; ty = g.y - py; }
+            const double dt_ = sqrt(tx * tx + ty * ty);
+            if (dt_ > 0) { qx += 2.0 * tx / dt_; qy += 2.0 * ty / dt_; }
+            double avx = 0.0, avy = 0.0; int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < kTopoMax; ++k) {
+                const int j = snei[at * kNeiStride + k];
+                const bool used = j >= 0;
+                const int tj = el * NPAD + (used ? j : 0);
+                const double x = px - sp[tj], y = py - sp[AG + tj];
+                const double d = sqrt(x * x + y * y);
+                if (used && d > 0 && d < P.r_avoid) {
+                    const double ux = x / d, uy = y / d;
+                    const double factor = 3.0 * (P.r_avoid / d - 1.0);
+                    qx += factor * ux; qy += factor * uy;
+                }
+                if (used) { avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt; }
+            }
+            if (cnt > 0) {
+                avx /= cnt; avy /= cnt;
+                qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
+            }
+        }
+        if (act) {
+            OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
+            reinterpret_cast<OT2 *>(P.prior_next)[(size_t)e * n_a + i] = o;
+        }
+    }
+
     // ---- observation rows, CPP:102-137,274-306, streamed out as (value, value) pairs with consecutive lanes
     // on consecutive addresses (the rows of this workgroup's environments are contiguous in HBM).  Two passes with
     // wave-uniform control flow: the 2*(self+topo)+2 head pairs of every row, then the G sensed-cell pairs.
@@ -1386,17 +1385,25 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
                 store_nt(&out[(size_t)r * PPR + q], o);
             };
-            if (T % HP == 0) {
+            // split B sits this pass out when there is a prior policy to evaluate (below): that dependent fp64 chain takes
+            // about as long as its share of the head pairs
+            const bool b_out = WPE > 1 && P.with_prior != 0;
+            const int HT = b_out ? T - AG : T;
+            const int ps = tid / AG, ps_b = (SB + WPE - (int)(blockIdx.x % WPE)) % WPE;     // physical split index; split B's
+            const int htid = b_out ? (ps < ps_b ? ps : ps - 1) * AG + at : tid;
+            if (b_out && sx == SB) {
+                // nothing
+            } else if (HT % HP == 0) {
                 // the usual case (HP = 16): a thread keeps its pair index q for all its rows, so the kind of pair it
                 // produces is decided once, outside the loop
-                const int q = tid % HP, blk = q >> 1, half = q & 1;
+                const int q = htid % HP, blk = q >> 1, half = q & 1;
                 const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
                 const int nslot = blk - P.with_self;
-                for (int r = tid / HP; r < rows; r += T / HP) head_pair(r, q, half, is_tgt, is_nei, nslot);
+                for (int r = htid / HP; r < rows; r += HT / HP) head_pair(r, q, half, is_tgt, is_nei, nslot);
             } else {
-                const int dr = T / HP, dq = T % HP;
-                int r = tid / HP, q = tid % HP;
-                for (int L = tid; L < total; L += T) {
+                const int dr = HT / HP, dq = HT % HP;
+                int r = htid / HP, q = htid % HP;
+                for (int L = htid; L < total; L += HT) {
                     const int blk = q >> 1, half = q & 1;
                     const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
                     head_pair(r, q, half, is_tgt, is_nei, blk - P.with_self);
@@ -1942,7 +1949,6 @@ void layout_t(KP &k)
     k.off_snei = take((size_t)AG * kNeiStride * 2);
     k.off_sncf = take((size_t)AG * 4);
     k.off_snear = take((size_t)NW * AG * 8);
-    k.off_pc = take((size_t)k.ngw * AG);
     k.smem_lat = (int)off;                           // lattice mode, no export
     k.off_obits = take((size_t)k.ngw * AG * 4);      // only launches that export the index scratch use it
     k.smem_lat_export = (int)off;
