@@ -364,24 +364,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     if constexpr (NW > 1) {                       // pair-mask accumulators (OR-ed into with LDS atomics)
         for (int k = sx; k < 5 * NW; k += WPE) pm[k * AG + at] = 0;
     }
-    double warm = 0.0;
     if (sx == 0) sflag[at] = 0;
     if (use_lat) {
         for (int q = tid; q < EPB * 64; q += T) {
             const int ek0 = blockIdx.x * EPB + (q >> 6);
             const LatEnv &Lq = P.lat[ek0 < P.n_env ? ek0 : P.n_env - 1];
             lrm[q] = Lq.rowmask[q & 63]; lrs[q] = Lq.rowstart[q & 63];
-        }
-        // lattice mode gathers the fp64 cells from global memory (nearest-cell merge, reward weights, observation
-        // values): one coalesced pass over this workgroup's cells up front brings them into L2 / L1 and the TLB, so the
-        // later per-lane gathers hit instead of each paying a scattered HBM access.  The values are only summed, and
-        // nothing waits for them before the nearest-cell merge (they are issued last, so earlier loads retire first).
-        for (int k = 0; k < EPB; ++k) {
-            const int ek0 = blockIdx.x * EPB + k;
-            const int ek = ek0 < P.n_env ? ek0 : P.n_env - 1;
-            const int ngk = P.n_g[ek];
-            const double2 *gq = P.cells_xy + (size_t)ek * P.ng_max;
-            for (int c = tid; c < ngk; c += T) { const double2 g = gq[c]; warm += g.x + g.y; }
         }
         for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
         for (int w = sx; w <= W; w += WPE) reinterpret_cast<unsigned *>(smem + P.off_cmask)[w * AG + at] = 0;   // rank-select bits (region unused until then)
@@ -916,7 +904,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     part_c[sx * AG + at] = bc;
-    asm volatile("" :: "v"(warm));       // keeps the warming loads of the prologue alive; long retired by now
     STAMP(16);
     EXIT_AT(4);
     __syncthreads();

@@ -45,7 +45,10 @@ class FusedPolicy:
         self._ctypes = ctypes
         self.lib = _lib.load()
         self.module = module
-        self.device = torch.device(device)
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError("FusedPolicy needs a cuda (HIP) device; there is no CPU path")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self.handle = None
         self.refresh()
 
@@ -57,7 +60,7 @@ class FusedPolicy:
         self.in_dim, self.hidden, self.act_dim = ws[0].shape[1], ws[0].shape[0], ws[6].shape[0]
         h = ct.c_void_p()
         rc = self.lib.swarm_policy_create(*[ct.c_void_p(w.data_ptr()) for w in ws], self.in_dim, self.hidden, self.act_dim,
-                                          self.device.index or 0, ct.byref(h))
+                                          self.device.index, ct.byref(h))
         if rc != 0:
             raise RuntimeError("swarm_policy_create failed: " + self.lib.swarm_policy_last_error().decode())
         self.close()
@@ -119,13 +122,29 @@ class DeviceReplay:
         if act_prior is not None:
             self.act_prior[s] = act_prior.reshape(n, -1)
         self.curr_i += n
-        if self.filled_i < self.capacity:
-            self.filled_i = min(self.capacity, self.filled_i + n)
+        if self.filled_i < self.capacity:                         # buffer_agent.py:122-123: the count may overshoot the
+            self.filled_i += n                                    # capacity by up to one block, exactly like the reference's
         if self.curr_i == self.capacity:
             self.curr_i = 0
 
     def sample(self, batch, generator=None):
-        idx = torch.randint(0, self.filled_i, (batch,), device=self.obs.device, generator=generator)
+        """Uniform with replacement over the rows written so far.  NOT the reference's rule (see sample_reference): that
+        one ignores how much of the buffer is filled and hands out never-written zero rows early in training."""
+        idx = torch.randint(0, min(self.filled_i, self.capacity), (batch,), device=self.obs.device, generator=generator)
+        return self.obs[idx], self.act[idx], self.rew[idx], self.next_obs[idx], self.done[idx], self.act_prior[idx]
+
+    def sample_reference(self, batch, generator=None, begin_index_range=300000):
+        """buffer_agent.py:145-154 as is: `batch` DISTINCT rows from the window
+        [begin, capacity - begin_index_range + begin), begin ~ U{0 .. begin_index_range - 1} -- a sliding window over the
+        whole allocation, whatever has been written.  Needs capacity > begin_index_range + batch (the reference allocates
+        2e4 steps x n_agents rows, train_assembly.py:66-69)."""
+        R = int(begin_index_range)
+        width = self.capacity - R
+        if width < batch:
+            raise ValueError("sample_reference: capacity %d leaves a window of %d rows for a batch of %d" % (self.capacity, width, batch))
+        dev = self.obs.device
+        begin = int(torch.randint(0, R, (1,), generator=generator, device=dev).item())
+        idx = torch.randperm(width, device=dev, generator=generator)[:batch] + begin
         return self.obs[idx], self.act[idx], self.rew[idx], self.next_obs[idx], self.done[idx], self.act_prior[idx]
 
 
@@ -175,22 +194,26 @@ class ChainedReplay:
 
 
 @torch.no_grad()
-def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, generator=None):
+def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, generator=None, host_rng=None):
     """Run `steps` env steps entirely on the device.
 
     env   : object with step_tensor(action[E,N,2]) -> (obs[E,N,D], rew[E,N], done[E,N], a_prior[E,N,2]|None)
             (marl_llm_amd.env.AssemblySwarmEnv, or a SwarmBatch through `step`)
     obs   : current observation tensor [E,N,D] (from reset_tensor / the previous rollout)
+    The epsilon coin of agents.py:89 is drawn on the HOST (numpy, like the reference's np.random.rand()): a device-side
+    draw would cost a host synchronisation every step.
     Returns (last obs, mean reward per step tensor [steps])."""
+    import numpy as np
     step = env.step_tensor if hasattr(env, "step_tensor") else env.step
     E, N, D = obs.shape
     rews = torch.zeros(steps, device=obs.device)
+    coin = host_rng if host_rng is not None else np.random
     for t in range(steps):
         x = obs.reshape(E * N, D)
         if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and isinstance(policy, FusedPolicy)):
             x = x.float()
         act = policy(x)
-        if epsilon > 0 and float(torch.rand((), device=obs.device, generator=generator)) < epsilon:   # agents.py:89-91
+        if epsilon > 0 and coin.rand() < epsilon:                                                      # agents.py:89-91
             act = torch.rand(act.shape, device=obs.device, generator=generator) * 2 - 1
         elif noise_scale > 0:                                                                          # agents.py:93-96
             act = (act + noise_scale * torch.randn(act.shape, device=obs.device, generator=generator)).clamp_(-1, 1)

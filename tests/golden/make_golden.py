@@ -11,7 +11,9 @@ the read-only reference tree, so ``ctypes.CDLL`` is redirected to the library or
 the same sources.  ``results.pkl`` (a missing large blob in the reference) is replaced by the synthetic
 shape set of marl_llm_amd/shapes.py written in the reference's pickle layout to a temp dir.
 
-Usage:  MPLBACKEND=Agg python tests/golden/make_golden.py
+Usage:  MPLBACKEND=Agg python tests/golden/make_golden.py        (round-1 fixtures g1..g5)
+        MPLBACKEND=Agg python tests/golden/make_golden.py r2     (round-2 fixtures: real shapes, thicker g2, reset
+                                                                  statistics, learner-side modules)
 """
 import ctypes
 import os
@@ -162,5 +164,127 @@ def main():
     print("done ->", HERE)
 
 
+def main_r2():
+    """Round-2 fixtures.  (a) the reference's own target shapes fig/*.png, tiled by marl_llm_amd.shape_images (the
+    reference's cv2 pipeline cannot run here: cv2 is not installed), fed to the reference env; (b) thicker g2 coverage:
+    3 steps at N = 256, periodic at N = 32 / 64, is_con_self_state = False at N = 64; (c) statistics of 10^4 reference
+    reset() calls; (d) outputs of the reference's MLPNetwork / ReplayBufferAgent (learner side of the device rollout)."""
+    from marl_llm_amd.shape_images import pack_cells_npz, process_folder
+    gym, Wrapper = import_reference_env()
+    tmp = tempfile.mkdtemp(prefix="golden_r2_")
+    rng = np.random.default_rng(2262)
+
+    # ---- (a) real shapes
+    fig = process_folder("/root/reference/fig")
+    pack_cells_npz(fig, os.path.join(HERE, "fig_cells.npz"))
+    pkl_fig = os.path.join(tmp, "results_fig.pkl")
+    save_results(pkl_fig, fig)
+    for n_a, mode, warm, seed in ((32, "prior", 100, 1), (32, "random", 0, 2), (64, "prior", 100, 3), (64, "prior", 100, 4),
+                                  (64, "random", 0, 5)):
+        np.random.seed(1000 + seed)
+        env = make_env(gym, Wrapper, n_a, pkl_fig)
+        rec = record_episode(env, 3, mode, rng, warm)
+        rec["shape_index"] = np.int64(int(np.argmax(env.env.shape_frequency)))
+        tag = f"g6_fig_n{n_a}_{mode}_s{seed}"
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+        print(tag, "shape", rec["shape_index"], "n_g", rec["grid"].shape[1], "in_shape", rec["in_flags"].sum(1),
+              "reward", rec["rew"].sum((1, 2)), "sensed max", (rec["sensed"] >= 0).sum(2).max())
+
+    # ---- (b) thicker g2 (synthetic shape set, as round 1)
+    pkl = os.path.join(tmp, "results.pkl")
+    save_results(pkl, synthetic_shape_set())
+    for n_a, mode, warm, steps, is_boundary, with_self, tag in (
+            (256, "prior", 100, 3, True, True, "g2_n256_prior3"),
+            (32, "random", 0, 3, False, True, "g2_n32_random_periodic"),
+            (64, "prior", 100, 3, False, True, "g2_n64_prior_periodic"),
+            (64, "prior", 100, 3, True, False, "g2_n64_prior_noself")):
+        np.random.seed(7000 + n_a)
+        env = make_env(gym, Wrapper, n_a, pkl, is_boundary, with_self)
+        rec = record_episode(env, steps, mode, rng, warm)
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+        print(tag, "in_shape", rec["in_flags"].sum(1), "reward", rec["rew"].sum((1, 2)))
+
+    # ---- (c) reset() statistics over 10^4 calls of the reference (assembly.py:156-219), N = 8, synthetic shape set
+    np.random.seed(31337)
+    env = make_env(gym, Wrapper, 8, pkl)
+    b = env.env
+    R = 10000
+    origins = [g.T for g in b.grid_center_origins] if hasattr(b, "grid_center_origins") else None
+    P = np.empty((R, 2, 8)); DP = np.empty((R, 2, 8)); OFF = np.empty((R, 2)); ANG = np.empty(R); SH = np.empty(R, np.int64)
+    prev = np.asarray(b.shape_frequency, np.float64).copy()
+    for k in range(R):
+        env.reset()
+        P[k] = b.p; DP[k] = b.dp
+        now = np.asarray(b.shape_frequency, np.float64)
+        SH[k] = int(np.argmax(now - prev)); prev = now.copy()
+        g = b.grid_center
+        OFF[k] = g.mean(axis=1)                              # the shape frame is centred, so the cells' mean is the offset
+        o = np.asarray(b.grid_center_origins[SH[k]], np.float64).T if origins is not None else None
+        # rotation angle from the first cell: g0 - offset = R(angle) o0
+        v = g[:, 0] - OFF[k]; u = o[:, 0]
+        ANG[k] = np.arctan2(u[0] * v[1] - u[1] * v[0], u[0] * v[0] + u[1] * v[1])
+    span = P.max(axis=2) - P.min(axis=2)
+    cluster = (span <= 2.0).all(axis=1)                       # the 2 x 2 box branch (:207-208); the arena branch spans more
+    q = np.linspace(0.0, 1.0, 21)
+    np.savez_compressed(os.path.join(HERE, "g7_reset_stats_n8.npz"), n_resets=np.int64(R), n_agents=np.int64(8),
+                        shape_hist=np.bincount(SH, minlength=len(b.l_cells)), n_cluster=np.int64(cluster.sum()),
+                        p_min=P.min(), p_max=P.max(), dp_min=DP.min(), dp_max=DP.max(),
+                        off_min=OFF.min(axis=0), off_max=OFF.max(axis=0), off_quant=np.quantile(OFF, q, axis=0),
+                        ang_quant=np.quantile(ANG, q), ang_min=ANG.min(), ang_max=ANG.max(),
+                        p_spread_quant=np.quantile(P[~cluster].reshape(-1), q), dp_quant=np.quantile(DP.reshape(-1), q),
+                        cluster_centre_quant=np.quantile(((P[cluster].max(axis=2) + P[cluster].min(axis=2)) / 2).reshape(-1), q),
+                        cluster_rel_quant=np.quantile((P[cluster] - P[cluster].mean(axis=2, keepdims=True)).reshape(-1), q),
+                        quantiles=q)
+    print("g7 reset stats: shapes", np.bincount(SH, minlength=len(b.l_cells)), "cluster", cluster.sum(), "of", R)
+
+    # ---- (d) learner-side modules the device rollout mirrors: MLPNetwork (networks.py:6-44), ReplayBufferAgent
+    #      (buffer_agent.py:13-128).  Imported from where they lie; only arrays are stored.
+    import importlib.util
+    import torch
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    nets = load("ref_networks", "/root/reference/marl_llm/algorithm/utils/networks.py")
+    buf = load("ref_buffer_agent", "/root/reference/marl_llm/algorithm/utils/buffer_agent.py")
+    torch.manual_seed(226)
+    net = nets.MLPNetwork(192, 2, hidden_dim=180, constrain_out=True)          # maddpg.py / agents.py:23-27 actor shape
+    with torch.no_grad():
+        for prm in net.parameters():                                           # spread the outputs over tanh's range
+            prm.mul_(3.0)
+    with np.load(os.path.join(HERE, "g2_n64_prior.npz")) as z:
+        real = z["obs"][0].T.astype(np.float32)                                # 64 real observation rows
+    X = np.concatenate([real, rng.normal(0, 0.5, (192, 192)).astype(np.float32)], axis=0)
+    with torch.no_grad():
+        Y = net(torch.from_numpy(X)).numpy()
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "g8_mlp_actor.npz"), X=X, Y=Y, **{k.replace(".", "_"): v for k, v in sd.items()})
+    print("g8 mlp: |Y| max", np.abs(Y).max(), "mean", np.abs(Y).mean())
+
+    # replay: 5 steps x 6 agents = 30 rows; blocks of 6, 6, 6, 6, 4 rows, then 6 (overflow rule :97-100), then 4, 6
+    rb = buf.ReplayBufferAgent(5, 6, slice(0, 6), state_dim=4, action_dim=2)
+    log = []
+    blocks = (6, 6, 6, 6, 4, 6, 4, 6)
+    ins = []
+    for t, n in enumerate(blocks):
+        o = rng.normal(size=(4, 6)); a = rng.normal(size=(2, 6)); r = rng.normal(size=(1, 6)); o2 = rng.normal(size=(4, 6))
+        d = (rng.uniform(size=(1, 6)) < 0.3); ap = rng.normal(size=(2, 6))
+        rb.push(o, a, r, o2, d, slice(0, n), ap)
+        ins.append(dict(o=o, a=a, r=r, o2=o2, d=d.astype(np.float64), ap=ap))
+        log.append((rb.curr_i, rb.filled_i, len(rb)))
+    np.savez_compressed(os.path.join(HERE, "g9_replay_push.npz"), blocks=np.array(blocks), log=np.array(log),
+                        obs=rb.obs_buffs, act=rb.ac_buffs, rew=rb.rew_buffs, next_obs=rb.next_obs_buffs, done=rb.done_buffs,
+                        act_prior=rb.ac_prior_buffs,
+                        **{f"in_{k}": np.stack([x[k] for x in ins]) for k in ("o", "a", "r", "o2", "d", "ap")})
+    print("g9 replay log (curr_i, filled_i, len):", log)
+    print("done ->", HERE)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":
+        main_r2()
+    else:
+        main()

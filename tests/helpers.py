@@ -7,8 +7,16 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def golden_files(pattern="g2_*.npz"):
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, pattern)))
+def golden_files(pattern=None):
+    """Recorded reference episodes: g2_* (synthetic shape set) and g6_* (the reference's own fig/*.png shapes)."""
+    pats = [pattern] if pattern else ["g2_*.npz", "g6_*.npz"]
+    return sorted(f for p in pats for f in glob.glob(os.path.join(GOLDEN_DIR, p)))
+
+
+def fig_shapes():
+    """The reference's seven target shapes (fig/*.png) as tiled by marl_llm_amd.shape_images; results.pkl layout."""
+    from marl_llm_amd.shape_images import unpack_cells_npz
+    return unpack_cells_npz(os.path.join(GOLDEN_DIR, "fig_cells.npz"))
 
 
 def load_golden(path):

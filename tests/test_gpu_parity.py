@@ -178,14 +178,24 @@ def test_small_caps(oracle, shapes):
         sb.close()
 
 
-def test_full_size_properties(oracle, shapes):
-    """BASELINE config 64 agents x 4096 envs: size-independent invariants over the whole batch plus an
-    exact oracle comparison on a sample of environments, in the product dtype (float32 obs)."""
+@pytest.mark.parametrize("n_a,n_env,env_offset", [
+    (64, 4096, 0),            # BASELINE config 2 (headline): one wavefront per env and split
+    (32, 1024, 0),            # BASELINE config 1: two envs per wavefront (EPB = 2)
+    (256, 4096, 0),           # BASELINE config 4: 1024-thread workgroups, LDS-atomic pair masks, dense O(N^2) path
+    (64, 4096, 3 * 4096),     # one rank's shard of BASELINE config 3 (64 x 32768 over 8 GPUs): envs [12288, 16384)
+    (32, 1023, 0),            # env count not divisible by the envs per workgroup: the `e >= n_env` tail lanes
+    (30, 1021, 0),            # the reference's default agent count, padded lanes inside every wavefront
+], ids=["64x4096", "32x1024", "256x4096", "64x4096_shard3", "32x1023", "30x1021"])
+def test_full_size_properties(oracle, shapes, n_a, n_env, env_offset):
+    """Every BASELINE shape at FULL size: size-independent invariants over the whole batch plus an exact oracle
+    comparison on a sample of environments (incl. the first and the last), in the product dtype (float32 obs)."""
     from marl_llm_amd.shapes import r_avoid_for
     from marl_llm_amd.synth import synthetic_batch
-    n_a, n_env = 64, 4096
     ra = r_avoid_for(n_a, shapes)
-    sy = synthetic_batch(n_env, n_a, shapes, seed=226, assembled_fraction=0.5)
+    sy = synthetic_batch(n_env, n_a, shapes, seed=226, assembled_fraction=0.5, env_offset=env_offset)
+    if env_offset:            # a shard is the same slice of the global generation (counter-based inputs)
+        ref = synthetic_batch(8, n_a, shapes, seed=226, assembled_fraction=0.5, env_offset=env_offset + 100)
+        assert np.array_equal(ref["p"], sy["p"][100:108]) and np.array_equal(ref["cells"], sy["cells"][100:108])
     sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra)
     sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"])
     sb.set_state(sy["p"], sy["dp"])
@@ -208,7 +218,9 @@ def test_full_size_properties(oracle, shapes):
     assert (sl[pad] == 0).all()
     assert ((sen[:, :, 1:] < 0) | (sen[:, :, :-1] >= 0)).all()               # valid slots form a prefix
     assert (np.diff(np.where(sen >= 0, sen, 1 << 20), axis=-1) > 0)[(sen[:, :, 1:] >= 0)].all()   # ascending cell index
-    for e in rng.choice(n_env, 24, replace=False):
+    assert sb.lattice_envs() == n_env                                       # tiled shapes: the row-walk path (N <= 64)
+    sample = np.unique(np.concatenate([[0, 1, n_env - 2, n_env - 1], rng.choice(n_env, 24 if n_a <= 64 else 10, replace=False)]))
+    for e in sample:
         g = sy["cells"][e][:, : sy["n_g"][e]]
         s = oracle.step(sy["p"][e], sy["dp"][e], np.ascontiguousarray(act[e].T), g, nei0[e], float(sy["l_cell"][e]), ra)
         assert np.array_equal(pg[e], s["p"]) and np.array_equal(dpg[e], s["dp"])

@@ -123,7 +123,7 @@ def test_device_rollout_and_replay(shapes):
     assert replay.act.abs().max() <= 1 and set(replay.rew.unique().tolist()).issubset({0.0, 1.0})
     # ring behaviour of buffer_agent.py:97-100: a block that would overflow is written flush with the end
     obs, _ = rollout(sb, policy, steps=2, obs=obs, replay=replay)
-    assert len(replay) == replay.capacity and replay.curr_i in (0, replay.capacity - n + n) or True
+    assert len(replay) == 6 * n and replay.curr_i == 0      # flush-with-the-end write; the fill counter overshoots like the reference's
     b = replay.sample(512)
     assert b[0].shape == (512, sb.obs_dim) and b[1].shape == (512, 2)
     sb.close()

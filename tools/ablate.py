@@ -34,7 +34,8 @@ def run(skip, n_a, E, sy, ra, state, steps=int(os.environ.get('ABLATE_STEPS', '6
 
 
 def main():
-    pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+    dbg = sys.argv[sys.argv.index("--dbg") + 1] if "--dbg" in sys.argv else None
+    pos = [a for a in sys.argv[1:] if not a.startswith('--') and a != dbg]
     n_a = int(pos[0]) if len(pos) > 0 else 64
     E = int(pos[1]) if len(pos) > 1 else 4096
     shapes = synthetic_shape_set()
@@ -47,6 +48,10 @@ def main():
         act = sb.step(act)[3]
     state = [x.cpu().numpy() for x in sb.get_state()]
     sb.close()
+    if "--dbg" in sys.argv:      # full kernel with one experiment switch (library built with -DSWARM_EXPERIMENT)
+        for ph in [0] + [int(a) for a in dbg.split(",")]:
+            print(f"  debug phase {ph:2d}: {run(ph << 8, n_a, E, sy, ra, state) * 1e3:8.1f} us")
+        return
     if "--cumulative" in sys.argv:
         # leave the kernel after segment k (debug phase 15): cumulative time / counters up to each point
         segs = ["loads+first barrier", "forces+prior+integrate", "pair masks", "ordered insertion", "cell walk",
