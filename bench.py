@@ -225,13 +225,13 @@ def survey_bytes(n_agents, n_g):
     return float(len(n_g)) * n_agents * 821.0 + 8.0 * float(np.sum(n_g))
 
 
-def measure(torch, n_a, E, state, steps, warmup, assemble_steps, seed, env_offset, device, barrier=None):
-    """Set up E envs of n_a agents on `device`, bring them to `state`, time `steps` steps.  Returns a dict (and the
-    SwarmBatch + inputs for the CPU baseline)."""
+def measure(torch, n_a, E, state, steps, warmup, assemble_steps, seed, env_offset, device, barrier=None, shapes=None):
+    """Set up E envs of n_a agents on `device`, bring them to `state`, return a closure that times `steps` steps (and the
+    SwarmBatch + inputs for the CPU baseline).  shapes: a results.pkl-layout dict (default: the synthetic shape set)."""
     from marl_llm_amd.batched import SwarmBatch
     from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
     from marl_llm_amd.synth import synthetic_batch
-    shapes = synthetic_shape_set()
+    shapes = synthetic_shape_set() if shapes is None else shapes
     r_avoid = r_avoid_for(n_a, shapes)
     sy = synthetic_batch(E, n_a, shapes, seed=seed, env_offset=env_offset)
     sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=r_avoid, device=device)
@@ -338,15 +338,21 @@ def main():
 
     others = []
     if rank == 0 and world == 1 and not args.no_other_configs:
-        for (oa, oe, ost, label) in ((32, 1024, "assembled", "BASELINE config 1"),
-                                     (64, 4096, "scatter", "headline shape, reset() state distribution, U(-1,1) actions"),
-                                     (256, 4096, "assembled", "BASELINE config 4 (dense O(N^2) neighbour path)"),
-                                     (64, 32768, "assembled", "BASELINE config 3's 8-GPU total on ONE GPU")):
-            osb, osy, _, otimed = measure(torch, oa, oe, ost, 50, 10, 100, args.seed, 0, f"cuda:{local_rank}")
+        from marl_llm_amd.shape_images import unpack_cells_npz
+        fig = unpack_cells_npz(os.path.join(ROOT, "tests", "golden", "fig_cells.npz"))
+        for (oa, oe, ost, osh, label) in (
+                (32, 1024, "assembled", None, "BASELINE config 1"),
+                (64, 4096, "scatter", None, "headline shape, reset() state distribution, U(-1,1) actions"),
+                (64, 4096, "assembled", fig, "headline shape on the reference's own fig/*.png target shapes (38-40 lattice "
+                                             "columns: 64-bit row masks instead of the synthetic set's 32-bit ones)"),
+                (256, 4096, "assembled", None, "BASELINE config 4 (dense O(N^2) neighbour path)"),
+                (64, 32768, "assembled", None, "BASELINE config 3's 8-GPU total on ONE GPU")):
+            osb, osy, _, otimed = measure(torch, oa, oe, ost, 50, 10, 100, args.seed, 0, f"cuda:{local_rank}", shapes=osh)
             odt, okms = otimed()
             us = okms * 1e3 / 50
             b = survey_bytes(oa, osy["n_g"])
-            others.append({"workload": f"assembly env, {oa} agents x {oe} envs, {ost} state", "what": label,
+            others.append({"workload": f"assembly env, {oa} agents x {oe} envs, {ost} state"
+                                       + (", reference fig shapes" if osh is not None else ""), "what": label,
                            "kernel_us": us, "agent_steps_per_s": oa * oe * 50 / odt,
                            "algorithmic_bytes_per_launch": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
             osb.close()

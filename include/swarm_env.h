@@ -192,6 +192,11 @@ void calculateActionPrior(double *p_input, double *dp_input, double *a_prior_inp
                           double *grid_center_input, int *neighbor_index_input, double d_sen,
                           double r_avoid, double l_cell, int topo_nei_max, int n_a, int n_g, int dim);
 
+/* The legacy entry points return void like the reference's; after a call, its status on the calling thread: 0 = ok,
+ * 1 = failed (outputs were filled with NaN, a line was written to stderr) and the reason (e.g. n_a > 256, no HIP device). */
+int  swarm_legacy_status(void);
+const char *swarm_legacy_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

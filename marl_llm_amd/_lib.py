@@ -31,7 +31,8 @@ BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", 
                    "swarm_get_state", "swarm_observe", "swarm_step", "swarm_get_indices",
                    "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_get_shape_index", "swarm_metrics", "swarm_rule_action")
 POLICY_SYMBOLS = ("swarm_policy_create", "swarm_policy_destroy", "swarm_policy_forward", "swarm_policy_forward_bf16", "swarm_policy_last_error")   # include/swarm_policy.h
-LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior")
+LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior",
+                  "swarm_legacy_status", "swarm_legacy_last_error")
 
 
 def load():
@@ -59,6 +60,8 @@ def load():
     lib.swarm_get_cells.argtypes = [vp, vp, vp]; lib.swarm_get_cells.restype = i32
     lib.swarm_get_shape_index.argtypes = [vp, vp]; lib.swarm_get_shape_index.restype = i32
     lib.swarm_metrics.argtypes = [vp, vp]; lib.swarm_metrics.restype = i32
+    lib.swarm_legacy_status.argtypes = []; lib.swarm_legacy_status.restype = i32
+    lib.swarm_legacy_last_error.argtypes = []; lib.swarm_legacy_last_error.restype = ctypes.c_char_p
     lib.swarm_rule_action.argtypes = [vp, vp]; lib.swarm_rule_action.restype = i32
     lib.swarm_policy_create.argtypes = [vp] * 8 + [i32] * 4 + [ctypes.POINTER(vp)]; lib.swarm_policy_create.restype = i32
     lib.swarm_policy_destroy.argtypes = [vp]; lib.swarm_policy_destroy.restype = None

@@ -27,6 +27,18 @@ namespace {
 
 std::mutex g_mu;
 
+// The reference's five entry points return void (AssemblyEnv.h:13-109), so a failure cannot be reported through them:
+// outputs are poisoned with NaN, a line goes to stderr, and the status / message of the last legacy call of this thread
+// can be read through swarm_legacy_status() / swarm_legacy_last_error().
+thread_local int g_legacy_status = 0;
+thread_local char g_legacy_msg[256] = "";
+void legacy_fail(const char *fn, const char *why)
+{
+    g_legacy_status = 1;
+    std::snprintf(g_legacy_msg, sizeof(g_legacy_msg), "%s: %s", fn, why);
+    std::fprintf(stderr, "libswarmenv: %s: %s\n", fn, why);
+}
+
 struct Arena {          // grow-only device scratch, reset per call
     char *base = nullptr;
     size_t cap = 0, used = 0;
@@ -225,10 +237,11 @@ void _get_observation(double *p_input, double *dp_input, double *heading_input, 
 {
     (void)heading_input; (void)Vel_max;
     std::lock_guard<std::mutex> lk(g_mu);
+    g_legacy_status = 0; g_legacy_msg[0] = 0;
     const char *fn = "_get_observation";
     const size_t nobs = (size_t)obs_dim_agent * n_a;
     auto bail = [&](const char *why) {
-        std::fprintf(stderr, "libswarmenv: %s: %s\n", fn, why);
+        legacy_fail(fn, why);
         fill_nan(obs_input, nobs);
     };
     if (dim != 2) return bail("only dim == 2 is supported");
@@ -280,8 +293,9 @@ void _get_reward(double *p_input, double *dp_input, double *heading_input, doubl
     (void)dp_input; (void)heading_input; (void)act_input; (void)occupied_index_input; (void)l_cell;
     (void)num_occupied_grid_max; (void)is_collide_b2b_input; (void)is_collide_b2w_input; (void)coefficients;
     std::lock_guard<std::mutex> lk(g_mu);
+    g_legacy_status = 0; g_legacy_msg[0] = 0;
     const char *fn = "_get_reward";
-    auto bail = [&](const char *why) { std::fprintf(stderr, "libswarmenv: %s: %s\n", fn, why); fill_nan(reward_input, (size_t)n_a); };
+    auto bail = [&](const char *why) { legacy_fail(fn, why); fill_nan(reward_input, (size_t)n_a); };
     if (dim != 2) return bail("only dim == 2 is supported");
     if (!device_ok(fn)) return bail("no device");
     const size_t N = (size_t)n_a;
@@ -307,8 +321,9 @@ void _sf_b2b_all(double *p_input, double *sf_b2b_input, double *d_b2b_edge_input
                  double *boundary_pos_input, double *d_b2b_center_input, int n_a, int dim, double k_ball, bool is_periodic)
 {
     std::lock_guard<std::mutex> lk(g_mu);
+    g_legacy_status = 0; g_legacy_msg[0] = 0;
     const char *fn = "_sf_b2b_all";
-    auto bail = [&](const char *why) { std::fprintf(stderr, "libswarmenv: %s: %s\n", fn, why); fill_nan(sf_b2b_input, (size_t)2 * n_a); };
+    auto bail = [&](const char *why) { legacy_fail(fn, why); fill_nan(sf_b2b_input, (size_t)2 * n_a); };
     if (dim != 2) return bail("only dim == 2 is supported");
     if (!device_ok(fn)) return bail("no device");
     const size_t N = (size_t)n_a;
@@ -332,8 +347,9 @@ void _get_dist_b2w(double *p_input, double *r_input, double *d_b2w_input, bool *
                    double *boundary_pos)
 {
     std::lock_guard<std::mutex> lk(g_mu);
+    g_legacy_status = 0; g_legacy_msg[0] = 0;
     const char *fn = "_get_dist_b2w";
-    auto bail = [&](const char *why) { std::fprintf(stderr, "libswarmenv: %s: %s\n", fn, why); fill_nan(d_b2w_input, (size_t)4 * n_a); };
+    auto bail = [&](const char *why) { legacy_fail(fn, why); fill_nan(d_b2w_input, (size_t)4 * n_a); };
     if (dim != 2) return bail("only dim == 2 is supported");
     if (!device_ok(fn)) return bail("no device");
     const size_t N = (size_t)n_a;
@@ -356,8 +372,9 @@ void calculateActionPrior(double *p_input, double *dp_input, double *a_prior_inp
 {
     (void)d_sen;
     std::lock_guard<std::mutex> lk(g_mu);
+    g_legacy_status = 0; g_legacy_msg[0] = 0;
     const char *fn = "calculateActionPrior";
-    auto bail = [&](const char *why) { std::fprintf(stderr, "libswarmenv: %s: %s\n", fn, why); fill_nan(a_prior_input, (size_t)2 * n_a); };
+    auto bail = [&](const char *why) { legacy_fail(fn, why); fill_nan(a_prior_input, (size_t)2 * n_a); };
     if (dim != 2) return bail("only dim == 2 is supported");
     if (!device_ok(fn)) return bail("no device");
     const size_t N = (size_t)n_a;
@@ -375,5 +392,8 @@ void calculateActionPrior(double *p_input, double *dp_input, double *a_prior_inp
     if (!ok(hipGetLastError(), fn, "launch") || !ok(hipMemcpy(a_prior_input, d_a, 2 * N * 8, hipMemcpyDeviceToHost), fn, "hipMemcpy"))
         return bail("kernel failed");
 }
+
+int swarm_legacy_status(void) { return g_legacy_status; }
+const char *swarm_legacy_last_error(void) { return g_legacy_msg; }
 
 }  // extern "C"

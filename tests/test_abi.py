@@ -110,3 +110,17 @@ def test_product_does_not_import_oracle():
             assert "liboracle" not in text and "oracle_py" not in text and "assembly_oracle" not in text, f
             for line in text.splitlines():
                 assert not re.match(r"\s*(from|import)\s+oracle\b", line), (f, line)
+
+
+def test_legacy_call_without_a_device_sets_the_status(lib):
+    """No GPU here: the legacy symbols poison their outputs and report through swarm_legacy_status()."""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a HIP device")
+    p = np.zeros((2, 4)); d = np.zeros((4, 4)); c = np.zeros((4, 4), np.uint8)
+    bnd = np.array([-2.4, 2.4, 2.4, -2.4])
+    dp_ = ctypes.POINTER(ctypes.c_double)
+    lib._get_dist_b2w(p.ctypes.data_as(dp_), np.full(4, 0.035).ctypes.data_as(dp_), d.ctypes.data_as(dp_),
+                      c.ctypes.data_as(ctypes.POINTER(ctypes.c_bool)), ctypes.c_int(2), ctypes.c_int(4), bnd.ctypes.data_as(dp_))
+    assert np.isnan(d).all() and lib.swarm_legacy_status() == 1 and b"_get_dist_b2w" in lib.swarm_legacy_last_error()

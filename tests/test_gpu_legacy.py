@@ -51,3 +51,17 @@ def test_legacy_symbols_match_oracle(legacy, oracle, shapes, n_a, cluster, perio
         s2 = ref_step(legacy, p, dp, act, g, a["neighbor_index"], l_cell, ra, is_boundary=not periodic, with_self=with_self)
         for k in s1:
             assert np.array_equal(s1[k], s2[k]), k
+
+
+def test_legacy_failure_is_reported(legacy, shapes):
+    """A configuration the kernels do not support (n_a > 256) must not pass silently: NaN outputs, a message on stderr
+    and a non-zero swarm_legacy_status() with the reason."""
+    from marl_llm_amd.shapes import r_avoid_for
+    rng = np.random.default_rng(0)
+    p, dp, g, l_cell = make_case(rng, shapes, 300, 0)
+    b = legacy.get_observation(p, dp, g, l_cell, r_avoid_for(300, shapes))
+    assert np.isnan(b["obs"]).all()
+    assert legacy.lib.swarm_legacy_status() == 1 and b"n_agents must be in [1, 256]" in legacy.lib.swarm_legacy_last_error()
+    p, dp, g, l_cell = make_case(rng, shapes, 8, 0)
+    legacy.get_observation(p, dp, g, l_cell, r_avoid_for(8, shapes))
+    assert legacy.lib.swarm_legacy_status() == 0

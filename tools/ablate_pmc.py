@@ -1,6 +1,14 @@
 #!/usr/bin/env python3
-"""Parse a rocprofv3 --pmc counter CSV of `ABLATE_STEPS=k python tools/ablate.py`: per-variant mean of a counter
-over the timed step dispatches (each variant = 5 warm-up + k timed launches of k_env<..., true>)."""
+"""Parse a rocprofv3 --pmc counter CSV of tools/ablate.py: per-variant mean of a counter over the timed step dispatches
+(each variant = 5 warm-up + k timed launches of k_env<..., true>).
+
+Collect it like this (GPU box): the step count is exported in the CALLING shell and python3 comes directly after `--` -- on
+this pool nothing may sit between the profiler and the interpreter (no `env VAR=...`, no shebang hop), because the
+profiler's preloaded library has already initialised the GPU and every such hop is an exec:
+    cd /tmp && export TMPDIR=/tmp ABLATE_STEPS=10
+    rocprofv3 --pmc SQ_INSTS_VALU -d out -o p --output-format csv -- python3 $REPO/tools/ablate.py
+    python3 $REPO/tools/ablate_pmc.py out/.../p_counter_collection.csv 10
+"""
 import collections
 import csv
 import sys

@@ -1,5 +1,11 @@
 #!/usr/bin/env python3
-"""Parse a rocprofv3 --pmc CSV of `ABLATE_STEPS=k python tools/ablate.py --cumulative`: counters up to each exit point."""
+"""Parse a rocprofv3 --pmc CSV of `tools/ablate.py --cumulative`: counters up to each exit point.
+
+Collect (GPU box; variable exported in the calling shell, python3 directly after `--`, see tools/ablate_pmc.py):
+    cd /tmp && export TMPDIR=/tmp ABLATE_STEPS=10
+    rocprofv3 --pmc SQ_INSTS_VALU -d out -o p --output-format csv -- python3 $REPO/tools/ablate.py --cumulative
+    python3 $REPO/tools/ablate_pmc_cum.py out/.../p_counter_collection.csv 10
+"""
 import collections, csv, sys
 path, k = sys.argv[1], int(sys.argv[2])
 segs = ["loads+first barrier", "forces+prior+integrate", "pair masks", "ordered insertion", "cell walk", "nearest merge",
