@@ -69,7 +69,7 @@ struct KP {
     int cxy_stride;            // double2 elements per env in LDS
     int cxq_stride;            // floats per env in the fp32 pair layout
     int g_stride;              // int16 elements per agent row in LDS
-    int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear;
+    int off_cxy, off_sp, off_cmask, off_sbits, off_obits, off_sidx, off_snei, off_sncf, off_snear, off_pc;
     int smem_lat, smem_lat_export, smem_generic;   // dynamic LDS bytes by launch kind
     double c_sen, c_near, c_occ, c_avoid, c_ball;     // squared-distance cut-offs
     double c_close, c_close2;  // (1.9 r_avoid)^2 and (3 r_avoid)^2 capped at c_sen: pre-selection radii of the neighbour insertion (any values are exact; the second is used for N > 128)
@@ -271,6 +271,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     short *lrs = reinterpret_cast<short *>(smem + P.off_lat + (size_t)EPB * 64 * 8);   // [EPB][64] row starts
     unsigned *cov = reinterpret_cast<unsigned *>(smem + P.off_cov);      // [EPB][ngw+1] cells within r_avoid/2 of ANY agent
     int *sflag = reinterpret_cast<int *>(smem + P.off_flag);             // [AG] per-lane exception flags
+    unsigned char *pc = smem + P.off_pc;                                 // [word][AG] kept-bit counts
 
     const int tid = threadIdx.x, lane = tid & 63;
     STAMP(0);
@@ -1004,16 +1005,22 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 }
                 asm volatile("" :: "v"(kw));
                 if (P.export_idx) obits[w * AG + at] = word & ~kw;
+                pc[w * AG + at] = (unsigned char)__popc(kw);
             }
         }
 
-        __syncthreads();
     }
     auto kept_word = [&](int w) -> unsigned {
         const unsigned word = sbits[w * AG + at];
         if (slow_filter || !in_shape) return word;
         return word & ~cov[el * (P.ngw + 1) + w];
     };
+    // kept-bit count of every word, dealt over the splits and shared through LDS: each of the WPE splits needs the counts of
+    // ALL words (list length, start of its rank range), and vector instructions -- not barriers -- are what this kernel
+    // runs out of, so nothing is counted four times
+    if (!slow_filter)
+        for (int w = sx; w < W; w += WPE) pc[w * AG + at] = (unsigned char)__popc(kept_word(w));
+    __syncthreads();
     STAMP(5);
     EXIT_AT(6);
 
@@ -1021,7 +1028,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // Each split emits the slots of its own words (rank = prefix of the kept-bit counts) and accumulates
     // partial sums; the sums are combined in split order below.
     int n_kept = 0;
-    for (int w = 0; w < W; ++w) n_kept += __popc(kept_word(w));
+    for (int w = 0; w < W; ++w) n_kept += pc[w * AG + at];
     const int G = P.g_max;
     const int n_sel = n_kept > G ? G : n_kept;
     // (1) which RANKS of the kept list survive the cap?  rank(s) = round(s * (n-1)/(G-1)), s = 0..G-1 (CPP:241-245),
@@ -1039,7 +1046,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const bool any_sub = __any(n_kept > G) != 0;
     int *sub_base = part_c;                  // [WPE][AG] first slot of each split's rank range, capped agents only (part_c is consumed)
     // (for N <= 64 `any_sub` is the same in every wave of the workgroup, so the barriers it guards are uniform)
-    if (NW == 1 && any_sub && !slow_filter) __syncthreads();      // every split is done reading part_c (nearest-cell merge)
     if (any_sub)
     for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
         FENCE();
@@ -1106,7 +1112,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         {
             int prefix = 0;
             for (int w = 0; w < W; ++w) {                              // ww = number of words whose running count is <= k0
-                prefix += __popc(kept_word(w));
+                prefix += pc[w * AG + at];
                 const bool le = prefix <= k0;
                 ww += le ? 1 : 0; within = le ? k0 - prefix : within;
             }
@@ -1311,8 +1317,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 const bool used = j >= 0;
                 const int tj = el * NPAD + (used ? j : 0);
                 const double x = px - sp[tj], y = py - sp[AG + tj];
-                const double d = sqrt(x * x + y * y);
-                if (used && d > 0 && d < P.r_avoid) {
+                const double d2n = x * x + y * y;
+                if (used && d2n > 0 && d2n < P.c_avoid) {            // 0 < d < r_avoid (CPP:1150-1160), d = sqrt(d2n): sqrt is monotonic
+                    const double d = sqrt(d2n);
                     const double ux = x / d, uy = y / d;
                     const double factor = 3.0 * (P.r_avoid / d - 1.0);
                     qx += factor * ux; qy += factor * uy;
@@ -1936,6 +1943,7 @@ void layout_t(KP &k)
     k.off_snei = take((size_t)AG * kNeiStride * 2);
     k.off_sncf = take((size_t)AG * 4);
     k.off_snear = take((size_t)NW * AG * 8);
+    k.off_pc = take((size_t)k.ngw * AG);
     k.smem_lat = (int)off;                           // lattice mode, no export
     k.off_obits = take((size_t)k.ngw * AG * 4);      // only launches that export the index scratch use it
     k.smem_lat_export = (int)off;

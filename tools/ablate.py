@@ -49,8 +49,9 @@ def main():
     state = [x.cpu().numpy() for x in sb.get_state()]
     sb.close()
     if "--dbg" in sys.argv:      # full kernel with one experiment switch (library built with -DSWARM_EXPERIMENT)
-        for ph in [0] + [int(a) for a in dbg.split(",")]:
-            print(f"  debug phase {ph:2d}: {run(ph << 8, n_a, E, sy, ra, state) * 1e3:8.1f} us")
+        for tok in ["0"] + dbg.split(","):                    # "phase" or "phase:extra"
+            ph, ex = (int(v) for v in (tok.split(":") + ["0"])[:2])
+            print(f"  debug phase {ph:2d} extra {ex:2d}: {run((ph << 8) | (ex << 12), n_a, E, sy, ra, state) * 1e3:8.1f} us")
         return
     if "--cumulative" in sys.argv:
         # leave the kernel after segment k (debug phase 15): cumulative time / counters up to each point
