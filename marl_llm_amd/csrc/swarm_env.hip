@@ -698,22 +698,25 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         auto row_run = [&](int b, float rho, double cut, unsigned *dst, bool dst_shared) {
             // columns of row b within lattice distance rho of (apf, bpf); exact test d2 < cut on the boundary columns
             const bool rowok = act && b >= 0 && b < nrows;
-            const float dy = (float)b - bpf;
-            const float ro = rho + lat_m, ri = rho - lat_m;
-            const float ho2 = ro * ro - dy * dy, hi2 = ri * ri - dy * dy;
+            const float dy = (float)b - bpf, dy2 = dy * dy;
+            const float ro = rho + lat_m, ri = rho - lat_m, ri2 = ri > 0.0f ? ri * ri : 0.0f;
+            const float ho2 = ro * ro - dy2;
             const bool any_o = rowok && ho2 > 0.0f;
             // raw v_sqrt_f32 (1 ulp): its error is far inside the margin
-            const float ho = __builtin_amdgcn_sqrtf(fmaxf(ho2, 0.0f)), hi = __builtin_amdgcn_sqrtf(fmaxf(hi2, 0.0f));
-            int ao0 = (int)ceilf(apf - ho), ao1 = (int)floorf(apf + ho);
-            int ai0 = (int)ceilf(apf - hi), ai1 = (int)floorf(apf + hi);
-            if (!(hi2 > 0.0f)) { ai0 = ao1 + 1; ai1 = ao1; }                 // no certain column in this row
+            const float ho = __builtin_amdgcn_sqrtf(fmaxf(ho2, 0.0f));
+            int ao0 = (int)ceilf(apf - ho), ao1 = (int)floorf(apf + ho);     // columns that may be in range
             ao0 = ao0 < 0 ? 0 : ao0; ao1 = ao1 > ncols - 1 ? ncols - 1 : ao1;
-            ai0 = ai0 < ao0 ? ao0 : ai0; ai1 = ai1 > ao1 ? ao1 : ai1;
             const int bq = b < 0 ? 0 : (b > 63 ? 63 : b);
             const MT rowm = any_o ? rowmask(bq) : (MT)0;
             const int rst = rs[bq];
-            MT acc = range(ai0, ai1);                                        // certain columns
-            MT bnd = range(ao0, ao1) & ~acc & rowm;                          // boundary columns: [ao0, ai0) and (ai1, ao1]
+            // The margin is far below one lattice step (the in-range band of a row is < 0.06 columns wide), so only the two
+            // END columns of the interval can sit in the uncertain band; every column between them is in range for certain.
+            // An end column is certain when its own model distance is inside the shrunk radius.
+            const float e0 = (float)ao0 - apf, e1 = (float)ao1 - apf;
+            const bool c0 = fmaf(e0, e0, dy2) < ri2, c1 = fmaf(e1, e1, dy2) < ri2;
+            MT acc = range(ao0, ao1);
+            MT bnd = (MT)((c0 ? (MT)0 : (MT)1 << (ao0 & (MB - 1))) | (c1 ? (MT)0 : (MT)1 << (ao1 & (MB - 1)))) & acc & rowm;   // boundary columns
+            acc &= ~bnd;
             while (__any(bnd != 0)) {
                 if (bnd != 0) {
                     const int a = ffs0(bnd);
