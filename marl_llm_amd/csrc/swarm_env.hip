@@ -481,7 +481,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             __syncthreads();
         }
     }
-    px = sp[at]; py = sp[AG + at]; vx = sp[2 * AG + at]; vy = sp[3 * AG + at];
+    px = sp[at]; py = sp[AG + at];            // (the velocities are re-read from LDS where the prior policy needs them:
+                                              // held in registers across the whole kernel they were spilled to scratch)
     STAMP(2);
     EXIT_AT(1);
 
@@ -1331,7 +1332,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
             if (cnt > 0) {
                 avx /= cnt; avy /= cnt;
-                qx += 2.0 * (avx - vx); qy += 2.0 * (avy - vy);
+                qx += 2.0 * (avx - sp[2 * AG + at]); qy += 2.0 * (avy - sp[3 * AG + at]);
             }
         }
         if (act) {
