@@ -151,18 +151,20 @@ int  swarm_metrics(swarm_env_t *h, double *out);
  * order; np.cos differs from the device cos by a few ulp, so parity is 1e-12 absolute, not bit-exact. */
 int  swarm_rule_action(swarm_env_t *h, double *action);
 
-/* Index scratch of the LAST swarm_observe/swarm_step (device pointers, any may be NULL).  The first
- * call that asks for sensed/occupied indices allocates the export buffers and re-runs the observation
- * pass on the current state to fill them. */
+/* Index scratch of the CURRENT state (device pointers, any may be NULL).  The step keeps neighbor_index / in_flags / the
+ * sensed and occupied lists in LDS and writes none of them to HBM; this call re-runs the observation pass on the current
+ * state with the export switched on (it recomputes the same caches from the same state: idempotent) and copies them out. */
 int  swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flags,
                        int32_t *sensed_index, int32_t *occupied_index);
 
 /* How many environments currently have target cells that are a row-major subset of a square lattice (the reference's
- * tiled shapes always are).  When ALL do (and n_agents <= 64), the sensed / occupied bit sets are built by a row walk
+ * tiled shapes always are, its seven fig/*.png included).  When ALL do (and n_agents <= 64), the sensed / occupied bit sets are built by a row walk
  * over the lattice instead of the all-cells scan; results are identical.  debug_flags bit 1 disables that path. */
 int  swarm_lattice_envs(const swarm_env_t *h);
 
-/* Roofline helper: algorithmic bytes one swarm_step moves (SURVEY.md section 8d accounting). */
+/* Roofline helper: bytes one swarm_step moves by SURVEY.md section 8d's accounting IN THIS BUILD'S DTYPES (fp64 state and
+ * cells); bench.py's `roofline` uses section 8d's own fp32 figure (821 B per agent-step + 8 B per cell) and reports this one
+ * beside it. */
 double swarm_step_algorithmic_bytes(const swarm_env_t *h);
 /* Time the last N launches?  No: timing lives in the caller (HIP events on the handle's stream).
  * These two record / read HIP events on that stream so a ctypes host needs no HIP binding. */
