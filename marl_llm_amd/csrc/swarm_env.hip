@@ -620,23 +620,71 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 #pragma unroll
             for (int w = 0; w < NW; ++w) cand[w] = few ? c1[w] : cand[w];
         }
-        // pass B: ordered insertion of the candidates, ascending j => ties keep the lower index first
+        // pass B: the topo nearest candidates in ascending (distance, index) order.  Each candidate's exact fp64 squared
+        // distance is turned into a sort key whose lowest 8 mantissa bits carry its index (non-negative doubles order like
+        // their bit patterns), and the key ripples through a sorted 7-entry register list with one v_min_f64 + one
+        // v_max_f64 per entry -- a third of the instructions of a compare-and-swap chain on (distance, index) pairs.  The
+        // keys differ from the distances by < 256 ulp, so the order is the reference's unless two of the 7 smallest
+        // distances agree in all but those bits (a true tie included): such a lane -- the 7th entry guards the boundary of
+        // the list -- redoes its insertion with the exact compare-and-swap chain below.
+        double dmin = INFINITY;
+        {
+            double nk[kTopoMax + 1];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            u64 h = cand[w];
-            while (h) {
-                const int jj = __ffsll((unsigned long long)h) - 1;
-                h &= h - 1;
-                double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
-                if (P.periodic) wrap_rel(rx, ry, P.w_half, P.h_half);
-                double cd = rx * rx + ry * ry; int cj = w * 64 + jj;
+            for (int k = 0; k <= kTopoMax; ++k) nk[k] = INFINITY;
 #pragma unroll
-                for (int k = 0; k < kTopoMax; ++k) {
-                    const bool sw = cd < nd[k];
-                    const double td = nd[k]; const int tjj = nj[k];
-                    nd[k] = sw ? cd : td; nj[k] = sw ? cj : tjj;
-                    cd = sw ? td : cd;    cj = sw ? tjj : cj;
+            for (int w = 0; w < NW; ++w) {
+                u64 h = cand[w];
+                while (h) {
+                    const int jj = __ffsll((unsigned long long)h) - 1;
+                    h &= h - 1;
+                    double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                    if (P.periodic) wrap_rel(rx, ry, P.w_half, P.h_half);
+                    const double cd = rx * rx + ry * ry;
+                    dmin = fmin(dmin, cd);
+                    double key = __builtin_bit_cast(double, (__builtin_bit_cast(u64, cd) & ~0xFFull) | (u64)(w * 64 + jj));
+#pragma unroll
+                    for (int k = 0; k <= kTopoMax; ++k) {
+                        const double lo = fmin(nk[k], key);
+                        key = fmax(nk[k], key);
+                        nk[k] = lo;
+                    }
                 }
+            }
+            bool amb = false;
+#pragma unroll
+            for (int k = 0; k < kTopoMax; ++k) {
+                const u64 kb = __builtin_bit_cast(u64, nk[k]), kn = __builtin_bit_cast(u64, nk[k + 1]);
+                const bool fin = nk[k] < INFINITY;
+                nj[k] = fin ? (int)(kb & 0xFFull) : -1;
+                amb = amb || (fin && nk[k + 1] < INFINITY && ((kb ^ kn) >> 8) == 0);
+            }
+            if (__any(amb)) {                     // rare: the exact (distance, index) insertion, ascending j => ties keep the lower index first
+                int xj[kTopoMax];
+#pragma unroll
+                for (int k = 0; k < kTopoMax; ++k) { nd[k] = INFINITY; xj[k] = -1; }
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    u64 h = amb ? cand[w] : 0;
+                    while (h) {
+                        const int jj = __ffsll((unsigned long long)h) - 1;
+                        h &= h - 1;
+                        double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                        if (P.periodic) wrap_rel(rx, ry, P.w_half, P.h_half);
+                        double cd = rx * rx + ry * ry; int cj = w * 64 + jj;
+                        bool ins = false;                 // once the candidate is placed the tail only shifts: an entry
+#pragma unroll                                            // carried down must pass equal distances (it was ahead of them)
+                        for (int k = 0; k < kTopoMax; ++k) {
+                            const bool sw = ins || cd < nd[k];
+                            ins = sw;
+                            const double td = nd[k]; const int tjj = xj[k];
+                            nd[k] = sw ? cd : td; xj[k] = sw ? cj : tjj;
+                            cd = sw ? td : cd;    cj = sw ? tjj : cj;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kTopoMax; ++k) nj[k] = amb ? xj[k] : nj[k];
             }
         }
         STAMP(13);
@@ -648,9 +696,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int k = 0; k < kTopoMax; ++k) {                      // CPP:459-491 collision test on the NEW list
             const bool used = k < P.topo && nj[k] >= 0;
             snei[at * kNeiStride + k] = (short)(used ? nj[k] : -1);
-            if (used && nd[k] < P.c_avoid) collision = true;
             if (P.export_small && act && k < P.topo) P.nei[((size_t)e * n_a + i) * P.topo + k] = used ? nj[k] : -1;
         }
+        // collision <=> some listed neighbour is closer than r_avoid (CPP:472-487) <=> the NEAREST candidate is (the list is
+        // sorted, and the nearest candidate is always listed)
+        collision = dmin < P.c_avoid;
         snei[at * kNeiStride + kTopoMax] = (short)(collision ? 1 : 0);
     }
     STAMP(3);

@@ -461,3 +461,51 @@ def test_wide_lattice_uses_64_bit_row_masks(oracle, n_a):
         for k in ("neighbor_index", "in_flags", "sensed_index", "occupied_index"):
             assert np.array_equal(idx[k][e].cpu().numpy(), s[k]), (e, k)
     sb.close()
+
+
+@pytest.mark.parametrize("n_a,periodic", [(64, False), (36, True), (200, False)])
+def test_exact_distance_ties_in_the_neighbour_list(oracle, shapes, n_a, periodic):
+    """Agents on an exactly representable square grid: every agent has several neighbours at EXACTLY equal distance, so the
+    order of its list is decided by the tie rule alone (lower index first -- the reference's std::sort leaves ties
+    unspecified, CPP:641; oracle and kernel both take the lower index).  Exercises the exact fallback of the key-based
+    neighbour selection (keys that agree in all but the index bits)."""
+    from marl_llm_amd.shapes import r_avoid_for
+    rng = np.random.default_rng(4)
+    ra = r_avoid_for(n_a, shapes)
+    side = int(np.ceil(np.sqrt(n_a)))
+    E = 3
+    cases = []
+    for e in range(E):
+        _, dp, g, l_cell = make_case(rng, shapes, n_a, 0)
+        pitch = [0.125, 0.1875, 0.25][e]                    # exact in binary: distances tie exactly
+        ij = rng.permutation(side * side)[:n_a]            # random index <-> grid position assignment
+        p = np.stack([(ij % side) * pitch - 1.0, (ij // side) * pitch - 1.0])
+        cases.append((np.ascontiguousarray(p), dp, g, l_cell))
+    ng_max = max(c[2].shape[1] for c in cases)
+    cells, n_g = _pad_cells([c[2] for c in cases], ng_max)
+    sb = _batch(n_env=E, n_agents=n_a, n_cells_max=ng_max, r_avoid=ra, is_boundary=not periodic, obs_dtype=torch.float64)
+    sb.set_cells(cells, n_g, [c[3] for c in cases])
+    sb.set_state(np.stack([c[0] for c in cases]), np.stack([c[1] for c in cases]))
+    obs = sb.observe().cpu().numpy()
+    idx = sb.indices()
+    ties = 0
+    for e, (p, dp, g, l_cell) in enumerate(cases):
+        o = oracle.get_observation(p, dp, g, l_cell, ra, is_periodic=periodic)
+        assert np.array_equal(idx["neighbor_index"][e].cpu().numpy(), o["neighbor_index"]), e
+        assert np.array_equal(obs[e], _to_rows(o["obs"])), e
+        nei = o["neighbor_index"]
+        for i in range(n_a):                                # count lists that really contain a tie
+            js = nei[i][nei[i] >= 0]
+            d = np.sum((p[:, js] - p[:, [i]]) ** 2, axis=0)
+            ties += int(len(d) > 1 and (np.diff(d) == 0).any())
+    assert ties > n_a                                       # most lists do
+    # one free step: rewards / priors on tied lists (collision flag = nearest listed neighbour)
+    act = torch.zeros((E, n_a, 2), dtype=torch.float64, device=sb.device)
+    obs2, rew, done, pri = sb.step(act)
+    for e, (p, dp, g, l_cell) in enumerate(cases):
+        o = oracle.get_observation(p, dp, g, l_cell, ra, is_periodic=periodic)
+        s = oracle.step(p, dp, np.zeros((2, n_a)), g, o["neighbor_index"], l_cell, ra, is_boundary=not periodic)
+        assert np.array_equal(obs2[e].cpu().numpy(), _to_rows(s["obs"])), e
+        assert np.array_equal(rew[e].cpu().numpy().astype(np.float64), s["reward"][0]), e
+        assert np.array_equal(pri[e].cpu().numpy(), _to_rows(s["a_prior"])), e
+    sb.close()
