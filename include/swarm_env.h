@@ -158,7 +158,7 @@ int  swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flag
                        int32_t *sensed_index, int32_t *occupied_index);
 
 /* How many environments currently have target cells that are a row-major subset of a square lattice (the reference's
- * tiled shapes always are, its seven fig/*.png included).  When ALL do (and n_agents <= 64), the sensed / occupied bit sets are built by a row walk
+ * tiled shapes always are, its seven fig PNGs included).  When ALL do (and n_agents <= 64), the sensed / occupied bit sets are built by a row walk
  * over the lattice instead of the all-cells scan; results are identical.  debug_flags bit 1 disables that path. */
 int  swarm_lattice_envs(const swarm_env_t *h);
 
