@@ -76,6 +76,9 @@ def parse():
                          "max-over-ranks run over gloo (numbers from such a run are meaningless)")
     ap.add_argument("--dry-spawn", action="store_true",
                     help="N>1 plumbing check without a GPU: ranks join gloo, report rank / world, exit")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="with --dry-spawn: this rank exits 3 at once (fail-fast test)")
+    ap.add_argument("--prewarm-ms", type=float, default=60.0,
+                    help="untimed steps of the same loop issued right before --warmup until this much GPU time has passed")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -89,30 +92,46 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, argv=None):
     """Start n fresh interpreters running this script as ranks 0..n-1 (children of this process, which never touches
-    the GPU; nothing is re-exec'd).  Rank 0 inherits stdout, so its ONE JSON line is this command's output."""
+    the GPU; nothing is re-exec'd).  Rank 0 inherits stdout, so its ONE JSON line is this command's output; the other
+    ranks' stdout goes to stderr (their failures must be readable).  All children are polled together: the first
+    non-zero exit kills the rest at once instead of leaving rank 0 blocked in a rendezvous until a timeout."""
     port = int(os.environ.get("MASTER_PORT", 0)) or free_port()
+    argv = sys.argv[1:] if argv is None else argv
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                    OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
     rc = 0
     deadline = time.time() + 1500
-    for p in procs:
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill(); code = 124
-        rc = rc or code
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    print(f"bench.py: rank {r} failed (exit code {code}); stopping the other ranks", file=sys.stderr)
+                    break
+        if time.time() > deadline:
+            rc = 124
+            print("bench.py: ranks still running at the 1500 s deadline", file=sys.stderr)
+        if live and rc == 0:
+            time.sleep(0.2)
     if rc:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        print(f"bench.py: a rank failed (exit code {rc})", file=sys.stderr)
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
     return rc
 
 
@@ -189,19 +208,24 @@ def run_cpu_leg(workers, state_path, n_agents, r_avoid, budget_s, steps_per_env=
     return {"value": steps * n_agents / wall, "envs": sum(r["envs"] for r in res), "seconds": wall, "kind": res[0]["kind"]}
 
 
-def cpu_baseline(sb, sy, r_avoid, n_agents, pool_all, pool_one, budget_s):
-    """Time the reference CPU path on a bounded sample of the SAME workload: environments of this batch, from the state
-    the GPU run starts from, advanced with prior-policy actions (what the GPU loop does).  kind = "reference": the
-    reference's own libAssemblyEnv.so (compiled unmodified, oracle/_ref) driven by a restatement of assembly.py's numpy
-    glue; kind = "port": our plain-C oracle when _ref is not present.  Two legs: one worker on one core, then P
-    independent worker processes (P = host cores), each stepping its own envs -- the reference itself is
-    single-threaded (c_lib.py:40-41 sets OMP_NUM_THREADS but the C++ has no pragma), so independent processes over
-    envs are how it would use a whole host."""
+def capture_cpu_state(sb, sy):
+    """Save the state the GPU run is about to start from (positions, velocities, neighbour lists, cells) for the CPU legs."""
     p, dp = [x.cpu().numpy() for x in sb.get_state()]
     nei = sb.indices(False, False)["neighbor_index"].cpu().numpy()
     fd, path = tempfile.mkstemp(suffix=".npz", prefix="bench_cpu_")
     os.close(fd)
     np.savez(path, p=p, dp=dp, nei=nei, cells=sy["cells"], n_g=sy["n_g"], l_cell=sy["l_cell"])
+    return path
+
+
+def cpu_baseline(path, r_avoid, n_agents, pool_all, pool_one, budget_s):
+    """Time the reference CPU path on a bounded sample of the SAME workload: environments of this batch, from the state
+    the GPU run starts from (`path`, capture_cpu_state), advanced with prior-policy actions (what the GPU loop does).
+    kind = "reference": the reference's own libAssemblyEnv.so (compiled unmodified, oracle/_ref) driven by a restatement
+    of assembly.py's numpy glue; kind = "port": our plain-C oracle when _ref is not present.  Two legs: one worker on
+    one core, then P independent worker processes (P = host cores), each stepping its own envs -- the reference itself
+    is single-threaded (c_lib.py:40-41 sets OMP_NUM_THREADS but the C++ has no pragma), so independent processes over
+    envs are how it would use a whole host."""
     try:
         one = run_cpu_leg(pool_one, path, n_agents, r_avoid, min(budget_s, 6.0))
         allc = run_cpu_leg(pool_all, path, n_agents, r_avoid, budget_s)
@@ -273,7 +297,70 @@ def measure(torch, n_a, E, state, steps, warmup, assemble_steps, seed, env_offse
             barrier()
         return time.perf_counter() - t0, kernel_ms
 
-    return sb, sy, r_avoid, timed
+    def prewarm(ms):
+        """Untimed steps of the same loop until `ms` of GPU time have passed (at least 20): the timed region then starts
+        at the clocks the chip holds under this load, whatever the host did before."""
+        nonlocal act
+        n, k = 0, 0
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        while n < 20 or (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(20):
+                act = one_step(k, act); k += 1
+            n += 20
+            torch.cuda.synchronize(dev)
+        return n
+
+    return sb, sy, r_avoid, timed, prewarm
+
+
+def extra_configs(torch, args, device):
+    """other_configs beyond the kernel shapes: the numpy drop-in API, the legacy shim, the device rollout (filled in below)."""
+    return []
+
+
+def claim_stdout():
+    """Rank 0's stdout must carry exactly ONE line: the JSON.  Native libraries (Gloo's "[Gloo] Rank 0 is connected
+    ..." banner, RCCL, the HIP runtime) print to file descriptor 1 behind Python's back, so fd 1 is pointed at stderr
+    for the whole run and the JSON line is written to a private duplicate of the original stdout."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
+def valu_bound(kernel_us, n_env):
+    """Second roofline entry: the bound that actually binds k_env -- vector-instruction issue.
+    instructions per launch by class come from the committed, source-hash-matched PMC summary (SQ_INSTS_VALU*, separate
+    --pmc passes); issue cost per class from profiles/r02/microbench_valu_*.txt (cycles per wave-instruction on one
+    SIMD with >= 2 resident waves: plain 32-bit 2.5, 3-operand / shift / compare / bit-count class 3.8-4.2, fp64 add /
+    mul / fma 4.4-4.9, conversions 4.1, transcendental 8.1).  frac = modelled issue cycles / (SIMDs x launch cycles at
+    2.4 GHz): the share of the launch during which the vector pipes are the resource in use."""
+    import glob
+    d = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "final_pmc_summary.json"))):
+        try:
+            c = json.load(open(f))
+        except Exception:
+            continue
+        if c.get("_source_sha256") == source_hash() and "SQ_INSTS_VALU" in c and c.get("_n_env", 4096) == n_env:
+            d = c
+    if d is None:
+        return {"bound": "valu", "insts_per_launch": None, "frac": None,
+                "note": "no PMC summary for this kernel source (tools/collect_profiles.sh regenerates it)"}
+    g = lambda k: float(d[k]["mean"]) if k in d else 0.0
+    total = g("SQ_INSTS_VALU")
+    f64 = g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
+    cvt, i64 = g("SQ_INSTS_VALU_CVT"), g("SQ_INSTS_VALU_INT64")
+    trans = g("SQ_INSTS_VALU_TRANS_F32") + g("SQ_INSTS_VALU_TRANS_F64")
+    typed = "SQ_INSTS_VALU_ADD_F64" in d
+    rest = total - f64 - cvt - i64 - trans
+    cycles = f64 * 4.6 + cvt * 4.1 + i64 * 4.4 + trans * 8.1 + rest * 3.3 if typed else total * 3.6
+    simds, clock = 256 * 4, 2.4e9
+    return {"bound": "valu", "insts_per_launch": total, "insts_per_env": total / n_env,
+            "issue_cycles_per_launch": cycles, "frac": cycles / (simds * kernel_us * 1e-6 * clock),
+            "mix": {"fp64": f64, "cvt": cvt, "int64": i64, "transcendental": trans, "other": rest} if typed else None,
+            "note": "modelled issue cycles (per-class counts x measured issue cost) / (1024 SIMDs x launch time x 2.4 GHz)"}
 
 
 def main():
@@ -290,16 +377,23 @@ def main():
     if world != args.gpus:
         print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a mislabelled run", file=sys.stderr)
         sys.exit(2)
+    out_stream = claim_stdout()                        # from here on fd 1 is stderr; the JSON goes to out_stream
 
     if args.dry_spawn:                                 # plumbing rehearsal: no GPU anywhere
         import torch
+        if args.dry_fail_rank == rank:
+            print(f"bench.py: rank {rank} exits 3 on request (--dry-fail-rank)", file=sys.stderr)
+            sys.exit(3)
         du.init(backend="gloo")
         du.barrier()
         top = du.max_over_ranks(float(rank))
         ranks = du.gather_to_rank0(torch.tensor([[rank, local_rank, world]], dtype=torch.int64))
+        per_rank = du.gather_to_rank0(torch.tensor([100.0 + rank], dtype=torch.float64))
         if rank == 0:
-            print(json.dumps({"dry_spawn": True, "n_gpus": world, "max_rank": top, "ranks": ranks[:, 0].tolist(),
-                              "local_ranks": ranks[:, 1].tolist()}), flush=True)
+            out_stream.write(json.dumps({"dry_spawn": True, "n_gpus": world, "max_rank": top, "ranks": ranks[:, 0].tolist(),
+                                         "local_ranks": ranks[:, 1].tolist(),
+                                         "per_rank_kernel_us": per_rank.tolist()}) + "\n")
+            out_stream.flush()
         du.barrier()
         du.shutdown()
         return
@@ -325,16 +419,23 @@ def main():
 
     n_a, E = args.agents, args.envs
     # weak scaling: every rank owns its own slice [rank*E, (rank+1)*E) of the global env range
-    sb, sy, r_avoid, timed = measure(torch, n_a, E, args.state, args.steps, args.warmup, args.assemble_steps, args.seed,
-                                     rank * E, f"cuda:{local_rank}", barrier)
-    cpu = None
-    if want_cpu:
-        cpu = cpu_baseline(sb, sy, r_avoid, n_a, pool_all, pool_one, args.cpu_seconds)
+    sb, sy, r_avoid, timed, prewarm = measure(torch, n_a, E, args.state, args.steps, args.warmup, args.assemble_steps,
+                                              args.seed, rank * E, f"cuda:{local_rank}", barrier)
+    cpu_state = None
+    if want_cpu:                                       # the state the timed GPU run starts from, for the CPU legs below
+        cpu_state = capture_cpu_state(sb, sy)
+    # The timed region runs FIRST, straight after >= 50 ms of untimed steps of the same loop (steady-state clocks): the
+    # CPU baseline keeps the host busy for ~16 s, after which a 3 ms timed region would start from idle GPU clocks.
+    n_prewarm = prewarm(args.prewarm_ms)
     dt, kernel_ms = timed()
     dt = du.max_over_ranks(dt, device="cpu" if (args.rehearse_one_gpu or world == 1) else sb.device)
+    per_rank_us = du.gather_to_rank0(torch.tensor([kernel_ms * 1e3 / args.steps], dtype=torch.float64))
     in_shape = float(sb.indices(False, False)["in_flags"].float().mean().item())
     alg64 = sb.algorithmic_bytes_per_step()
     sb.close()
+    cpu = None
+    if want_cpu:
+        cpu = cpu_baseline(cpu_state, r_avoid, n_a, pool_all, pool_one, args.cpu_seconds)
 
     others = []
     if rank == 0 and world == 1 and not args.no_other_configs:
@@ -347,7 +448,8 @@ def main():
                                              "columns: 64-bit row masks instead of the synthetic set's 32-bit ones)"),
                 (256, 4096, "assembled", None, "BASELINE config 4 (dense O(N^2) neighbour path)"),
                 (64, 32768, "assembled", None, "BASELINE config 3's 8-GPU total on ONE GPU")):
-            osb, osy, _, otimed = measure(torch, oa, oe, ost, 50, 10, 100, args.seed, 0, f"cuda:{local_rank}", shapes=osh)
+            osb, osy, _, otimed, oprewarm = measure(torch, oa, oe, ost, 50, 10, 100, args.seed, 0, f"cuda:{local_rank}", shapes=osh)
+            oprewarm(args.prewarm_ms)
             odt, okms = otimed()
             us = okms * 1e3 / 50
             b = survey_bytes(oa, osy["n_g"])
@@ -358,6 +460,7 @@ def main():
             osb.close()
             del osb, osy
             torch.cuda.empty_cache()
+        others.extend(extra_configs(torch, args, f"cuda:{local_rank}"))
 
     if rank == 0:
         total_agent_steps = float(world) * E * n_a * args.steps
@@ -372,7 +475,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (state, every index / flag / reward decision) + f32 (obs, prior, action I/O, pre-filters)",
-            "data": "synthetic",
+            "data": "synthetic", "prewarm_steps": n_prewarm,
+            "per_rank_kernel_us": per_rank_us.tolist(),
             "config": {"workload": workload,
                        "agents": n_a, "envs_per_gpu": E, "envs_total": E * world, "obs_dtype": "f32",
                        "state_dtype": "f64", "in_shape_fraction": round(in_shape, 3), "seed": args.seed,
@@ -384,7 +488,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg,
                          "algorithmic_bytes_note": "SURVEY 8(d): 821 B per agent-step + 8 B per target cell per env",
                          "bytes_per_launch_this_build_dtypes": alg64,
-                         "kernel_source_sha256": source_hash()},
+                         "kernel_source_sha256": source_hash(),
+                         "secondary": valu_bound(launch_s * 1e6, E)},
         }
         if cpu is not None:
             cpu["gpu_over_cpu"] = value / cpu["value"]
@@ -392,7 +497,8 @@ def main():
             out["cpu_baseline"] = cpu
         if others:
             out["other_configs"] = others
-        print(json.dumps(out), flush=True)
+        out_stream.write(json.dumps(out) + "\n")
+        out_stream.flush()
     du.barrier()
     du.shutdown()
 

@@ -624,9 +624,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         // distance is turned into a sort key whose lowest 8 mantissa bits carry its index (non-negative doubles order like
         // their bit patterns), and the key ripples through a sorted 7-entry register list with one v_min_f64 + one
         // v_max_f64 per entry -- a third of the instructions of a compare-and-swap chain on (distance, index) pairs.  The
-        // keys differ from the distances by < 256 ulp, so the order is the reference's unless two of the 7 smallest
-        // distances agree in all but those bits (a true tie included): such a lane -- the 7th entry guards the boundary of
-        // the list -- redoes its insertion with the exact compare-and-swap chain below.
+        // keys differ from the squared distances by < 256 ulp, so the order is the reference's (by norm = sqrt, monotonic)
+        // unless two of the 7 smallest squared distances agree in all but those bits (a true tie and every pair whose
+        // square roots could coincide included): such a lane -- the 7th entry guards the boundary of the list -- redoes its
+        // insertion with the exact compare-and-swap chain on the norms below.
         double dmin = INFINITY;
         {
             double nk[kTopoMax + 1];
@@ -671,7 +672,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         h &= h - 1;
                         double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
                         if (P.periodic) wrap_rel(rx, ry, P.w_half, P.h_half);
-                        double cd = rx * rx + ry * ry; int cj = w * 64 + jj;
+                        // the reference sorts by the NORM (CPP:636-641): two squared distances a few ulp apart can round to the
+                        // same sqrt and are then a tie (lower index first), so this path compares the norms themselves
+                        double cd = sqrt(rx * rx + ry * ry); int cj = w * 64 + jj;
                         bool ins = false;                 // once the candidate is placed the tail only shifts: an entry
 #pragma unroll                                            // carried down must pass equal distances (it was ahead of them)
                         for (int k = 0; k < kTopoMax; ++k) {

@@ -201,7 +201,8 @@ def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, 
             (marl_llm_amd.env.AssemblySwarmEnv, or a SwarmBatch through `step`)
     obs   : current observation tensor [E,N,D] (from reset_tensor / the previous rollout)
     The epsilon coin of agents.py:89 is drawn on the HOST (numpy, like the reference's np.random.rand()): a device-side
-    draw would cost a host synchronisation every step.
+    draw would cost a host synchronisation every step.  `host_rng`: anything with a .random() method -- the np.random
+    module (default), a RandomState or a Generator (np.random.default_rng).
     Returns (last obs, mean reward per step tensor [steps])."""
     import numpy as np
     step = env.step_tensor if hasattr(env, "step_tensor") else env.step
@@ -213,7 +214,7 @@ def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, 
         if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and isinstance(policy, FusedPolicy)):
             x = x.float()
         act = policy(x)
-        if epsilon > 0 and coin.rand() < epsilon:                                                      # agents.py:89-91
+        if epsilon > 0 and coin.random() < epsilon:                                                      # agents.py:89-91
             act = torch.rand(act.shape, device=obs.device, generator=generator) * 2 - 1
         elif noise_scale > 0:                                                                          # agents.py:93-96
             act = (act + noise_scale * torch.randn(act.shape, device=obs.device, generator=generator)).clamp_(-1, 1)
