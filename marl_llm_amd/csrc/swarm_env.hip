@@ -84,7 +84,12 @@ struct KP {
     int dbg_phase, dbg_extra;  // diagnostics only (tools/ablate.py): run phase dbg_phase dbg_extra EXTRA times; the
                                // phases are idempotent, so results are unchanged and the extra cost is the phase's cost
     int off_cxyf, off_partc, off_lat, off_cov, off_flag;
-    int lattice;               // every env's cells are a lattice subset: row-run path for sensed / occupied bits
+    // lattice (row-space) launches only: per-agent frame, per (window row, agent) column masks / first cell index, per-agent
+    // row counts, the agent permutation of the list phase, the fp32 reward verdicts, the occupied columns (export only)
+    int off_hdr, off_srow, off_sbase, off_pcr, off_perm, off_rres, off_orow;
+    float rew_ga_lat, rew_gb_lat;   // guard band of the fp32 reward decision in lattice steps (see swarm_create)
+    float rew_thr_k;           // 0.05 / d_sen: the reward's |v| threshold in lattice steps is rew_thr_k * (d_sen / l)
+    int lattice;               // every env's cells are a lattice subset whose sensing window is <= 15 rows: row-space path
     int lat_rw, lat_cw;        // row half-windows (lattice steps) for d_sen and r_avoid/2
     int lat_nrs, lat_nrc;      // rows a radius can touch: floor(2 (rho_max + margin)) + 1, for d_sen and r_avoid/2
     int lat_n32;               // every env's lattice has <= 32 columns: 32-bit row masks
@@ -245,7 +250,9 @@ __device__ __forceinline__ float psi_u_f32(float u)
     return c;
 }
 
-template <int NPAD, typename OT, bool DO_STEP>
+// LAT: every env's target cells are a lattice subset (host-detected, KP::lattice) -- a compile-time switch, so that each
+// instantiation carries ONE cell path and stays inside the 64 KB instruction cache.
+template <int NPAD, typename OT, bool DO_STEP, bool LAT>
 __global__ void __launch_bounds__(Geo<NPAD>::T, Geo<NPAD>::WPS)
 k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__restrict__ obs,
       float *__restrict__ reward, uint8_t *__restrict__ done, OT *__restrict__ a_prior)
@@ -272,6 +279,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     unsigned *cov = reinterpret_cast<unsigned *>(smem + P.off_cov);      // [EPB][ngw+1] cells within r_avoid/2 of ANY agent
     int *sflag = reinterpret_cast<int *>(smem + P.off_flag);             // [AG] per-lane exception flags
     unsigned char *pc = smem + P.off_pc;                                 // [word][AG] kept-bit counts
+    // row-space representation of the lattice path (LAT): window row t of agent thread `at` = lattice row b0 + t, its
+    // columns are stored relative to the agent's first column ca0 (<= 17 columns are ever in range: 32-bit words)
+    constexpr int NRC = 16;                                              // window rows stored per agent (lat_nrs <= 15)
+    float4 *hdr = reinterpret_cast<float4 *>(smem + P.off_hdr);          // [AG] {apr = a - ca0, bpr = b - b0, b0, ca0} (last two: ints)
+    unsigned *srow = reinterpret_cast<unsigned *>(smem + P.off_srow);    // [NRC][AG] sensed, then kept columns of window row t
+    unsigned short *sbase = reinterpret_cast<unsigned short *>(smem + P.off_sbase);   // [NRC][AG] cell index of column ca0 in that row
+    unsigned char *pcr = smem + P.off_pcr;                               // [AG][NRC] kept cells per window row
+    u64 *covrow = reinterpret_cast<u64 *>(smem + P.off_cov);             // [EPB][64] columns within r_avoid/2 of ANY agent, per lattice row
+    unsigned char *perm = smem + P.off_perm;                             // [T/64][64] agent threads in ascending list length (per wave)
+    unsigned char *rres = smem + P.off_rres;                             // [AG] fp32 reward verdict: bit 0 uniform, bit 1 unsure
+    unsigned *orow = reinterpret_cast<unsigned *>(smem + P.off_orow);    // [NRC][AG] occupied columns (export launches only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     STAMP(0);
@@ -343,8 +361,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // ---- generic (non-lattice) mode: stage an fp32 copy of the target cells (ENV: grid_center (2, n_g)) in LDS, laid
     // out per pair of cells {xa, xb, ya, yb} for packed arithmetic, padded with a sentinel (fp32: +inf).  The lattice
     // walk needs no cell coordinates except on its rare exact paths, which read the fp64 cells from global memory.
-    const bool use_lat = P.lattice != 0;
-    if (!use_lat)
+    constexpr bool use_lat = LAT;
+    if constexpr (!use_lat)
     for (int rep = 0, reps = REPS(9); rep < reps; ++rep)
     for (int k = 0; k < EPB; ++k) {
         FENCE();
@@ -366,15 +384,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int k = sx; k < 5 * NW; k += WPE) pm[k * AG + at] = 0;
     }
     if (sx == 0) sflag[at] = 0;
-    if (use_lat) {
+    if constexpr (use_lat) {
         for (int q = tid; q < EPB * 64; q += T) {
             const int ek0 = blockIdx.x * EPB + (q >> 6);
             const LatEnv &Lq = P.lat[ek0 < P.n_env ? ek0 : P.n_env - 1];
             lrm[q] = Lq.rowmask[q & 63]; lrs[q] = Lq.rowstart[q & 63];
+            covrow[q] = 0;                                                   // covered columns are OR-ed in
         }
-        for (int w = sx; w <= W; w += WPE) sbits[w * AG + at] = 0;          // sensed runs are OR-ed in
-        for (int w = sx; w <= W; w += WPE) reinterpret_cast<unsigned *>(smem + P.off_cmask)[w * AG + at] = 0;   // rank-select bits (region unused until then)
-        for (int q = tid; q < EPB * (P.ngw + 1); q += T) cov[q] = 0;
+        if (sx == WPE - 1) reinterpret_cast<uint4 *>(pcr)[at] = uint4{0u, 0u, 0u, 0u};   // rows past lat_nrs stay empty
     }
     // ---- forces + integration (split A).  For N <= 64 split A is ONE wavefront holding every agent of its environment(s):
     // it parks the old positions in LDS for its own contact-spring loop (a wavefront's LDS operations execute in order,
@@ -720,19 +737,32 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const bool wave_exact = (P.force_exact != 0) || (__any(lane_far) != 0);
     float best32 = INFINITY, second32 = INFINITY; int bc = 0;
     const f2v pxx = {pxf, pxf}, pyy = {pyf, pyf};
-    if (use_lat) {
+    if constexpr (use_lat) {
         // ---- lattice path.  Row b of the lattice holds the cells of columns rowmask[b]; the columns within
         // lattice distance rho of the agent form an interval.  Columns inside the radius shrunk by the margin lat_m
         // are in range for certain, columns outside the radius grown by lat_m are not; the (rare) columns in between
         // are decided by the reference's exact fp64 test on the stored coordinates.  lat_m = 5x the model's error
         // bound: per coordinate 2^-24 |coordinate| (fp32 cast of the fp64 lattice coordinate) + 1e-6 (lattice fit
         // tolerance of detect_lattice) + ~1e-6 (fp32 radius / sqrt roundings), i.e. < 2e-5 steps for |coordinate| <= 128.
-        // Selected cells of a row are consecutive cell indices: one run OR-ed into the bit set.
+        // The sets stay in ROW space: window row t of an agent is lattice row b0 + t, its in-range columns are kept as a
+        // 32-bit word relative to the agent's first possible column ca0 (the window is <= 17 columns wide).
         const LatEnv &L = P.lat[es];
-        const float apf = (float)((px - L.ox) * L.uxi + (py - L.oy) * L.uyi);
-        const float bpf = (float)((px - L.ox) * L.vxi + (py - L.oy) * L.vyi);
+        const double apd = (px - L.ox) * L.uxi + (py - L.oy) * L.uyi;
+        const double bpd = (px - L.ox) * L.vxi + (py - L.oy) * L.vyi;
+        const float apf = (float)apd, bpf = (float)bpd;
         const int nrows = L.nrows, ncols = L.ncols;
         const float lat_m = fmaxf(1e-4f, 8e-7f * fmaxf(fabsf(apf), fabsf(bpf)));
+        // first window row / first window column: no row below b0s and no column below ca0 can be in range (the interval
+        // of a row starts at ceil(a - h) with h <= R + margin)
+        const int b0s = (int)ceilf(bpf - (L.R + 2.0f * lat_m));
+        int ca0 = (int)ceilf(apf - (L.R + 2.0f * lat_m));
+        ca0 = ca0 < 0 ? 0 : (ca0 > 63 ? 63 : ca0);
+        if (sx == 0) {
+            float4 hq;
+            hq.x = (float)(apd - (double)ca0); hq.y = (float)(bpd - (double)b0s);
+            hq.z = __int_as_float(b0s); hq.w = __int_as_float(ca0);
+            hdr[at] = hq;
+        }
         const u64 *rm = lrm + el * 64;
         const short *rs = lrs + el * 64;
         // Rows are dealt over the splits other than B: B runs the ordered neighbour insertion meanwhile (about one
@@ -749,7 +779,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         auto ffs0 = [](MT v) -> int { return (MB == 32 ? __ffs((unsigned)v) : __ffsll((unsigned long long)v)) - 1; };
         // columns lo..hi inclusive, 0 <= lo, hi <= MB-1; empty when hi < lo
         auto range = [](int lo, int hi) -> MT { return hi >= lo ? (MT)((~(MT)0 >> (MB - 1 - hi)) & (~(MT)0 << lo)) : (MT)0; };
-        auto row_run = [&](int b, float rho, double cut, unsigned *dst, bool dst_shared) {
+        auto row_sel = [&](int b, float rho, double cut) -> MT {
             // columns of row b within lattice distance rho of (apf, bpf); exact test d2 < cut on the boundary columns
             const bool rowok = act && b >= 0 && b < nrows;
             const float dy = (float)b - bpf, dy2 = dy * dy;
@@ -781,38 +811,24 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     if (ex * ex + ey * ey < cut) acc |= (MT)1 << a;
                 }
             }
-            const MT sel = rowm & acc;
-            if (sel != 0) {
-                const int a0 = ffs0(sel);
-                const int idx0 = rst + popc(rowm & (MT)(((MT)1 << a0) - 1));
-                const int cnt = popc(sel);
-                // bits [idx0, idx0 + cnt) of the cell-index bit set
-                if constexpr (MB == 32) {                                    // cnt <= 32: at most two words
-                    const int wq = idx0 >> 5, off = idx0 & 31;
-                    const unsigned ones = cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
-                    const unsigned m_lo = ones << off, m_hi = off ? ones >> (32 - off) : 0u;
-                    atomicOr(dst_shared ? &dst[wq] : &dst[wq * AG + at], m_lo);
-                    if (m_hi) atomicOr(dst_shared ? &dst[wq + 1] : &dst[(wq + 1) * AG + at], m_hi);
-                } else {                                                     // cnt <= 64: up to three words
-                    int pos = idx0, left = cnt;
-                    while (left > 0) {
-                        const int wq = pos >> 5, off = pos & 31;
-                        const int take = left < 32 - off ? left : 32 - off;
-                        const unsigned m = (take >= 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << off;
-                        atomicOr(dst_shared ? &dst[wq] : &dst[wq * AG + at], m);
-                        pos += take; left -= take;
-                    }
-                }
-            }
+            return rowm & acc;
         };
         for (int rep = 0, reps = REPS(3); rep < reps; ++rep) {
             FENCE();
             // rows b with |b - bpf| < rho + margin: the first is ceil(bpf - rho - margin), at most floor(2 (rho + margin)) + 1
             // of them (lat_nrs / lat_nrc: that count for the largest rho of any env)
-            const int b0s = (int)ceilf(bpf - (L.R + 2.0f * lat_m));
-            for (int t = wr; t < P.lat_nrs; t += WS) row_run(b0s + t, L.R, P.c_sen, sbits, false);
+            for (int t = wr; t < P.lat_nrs; t += WS)
+                srow[t * AG + at] = (unsigned)(row_sel(b0s + t, L.R, P.c_sen) >> ca0);
+            // the same walk with radius r_avoid/2: the env's "covered by any agent" columns, per lattice row
             const int b0c = (int)ceilf(bpf - (L.Rc + 2.0f * lat_m));
-            for (int t = wr; t < P.lat_nrc; t += WS) row_run(b0c + t, L.Rc, P.c_occ, cov + el * (P.ngw + 1), true);
+            for (int t = wr; t < P.lat_nrc; t += WS) {
+                const MT selc = row_sel(b0c + t, L.Rc, P.c_occ);
+                const int bq = b0c + t < 0 ? 0 : (b0c + t > 63 ? 63 : b0c + t);         // selc == 0 outside the lattice
+                if (selc != 0) {
+                    if constexpr (MB == 32) atomicOr(reinterpret_cast<unsigned *>(&covrow[el * 64 + bq]), (unsigned)selc);
+                    else atomicOr(reinterpret_cast<unsigned long long *>(&covrow[el * 64 + bq]), (unsigned long long)selc);
+                }
+            }
             // nearest cell (CPP:858-908) from the lattice too: in row b the nearest cell is the set column closest to
             // the agent's column coordinate, on either side of it -- two candidates per row, rows dealt over the splits.
             // best / runner-up are tracked in lattice units; a runner-up within the model's error of the best sends the
