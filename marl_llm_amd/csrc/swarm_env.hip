@@ -284,7 +284,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     constexpr int NRC = 16;                                              // window rows stored per agent (lat_nrs <= 15)
     float4 *hdr = reinterpret_cast<float4 *>(smem + P.off_hdr);          // [AG] {apr = a - ca0, bpr = b - b0, b0, ca0} (last two: ints)
     unsigned *srow = reinterpret_cast<unsigned *>(smem + P.off_srow);    // [NRC][AG] sensed, then kept columns of window row t
-    unsigned short *sbase = reinterpret_cast<unsigned short *>(smem + P.off_sbase);   // [NRC][AG] cell index of column ca0 in that row
+    unsigned short *rbase = reinterpret_cast<unsigned short *>(smem + P.off_sbase);   // [NRC][AG] cell index of column ca0 in that row
     unsigned char *pcr = smem + P.off_pcr;                               // [AG][NRC] kept cells per window row
     u64 *covrow = reinterpret_cast<u64 *>(smem + P.off_cov);             // [EPB][64] columns within r_avoid/2 of ANY agent, per lattice row
     unsigned char *perm = smem + P.off_perm;                             // [T/64][64] agent threads in ascending list length (per wave)
@@ -1007,6 +1007,245 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     STAMP(4);
     EXIT_AT(5);
 
+    const int G = P.g_max;
+    int n_sel = 0;                                   // length of this agent thread's capped list
+    bool uniform = false, unsure = false;            // split A: fp32 verdict of the exploration reward / "redo it exactly"
+    if constexpr (LAT) {
+    // ================================================================================================================
+    // Lattice path, row space.  After the walk every (window row t, agent) holds its sensed columns as a 32-bit word
+    // relative to the agent's column ca0, and covrow[b] holds the env's covered columns of lattice row b.
+    // (K) kept = in_shape ? sensed & ~covered : sensed (CPP:150,209-216), the row's first cell index and its kept count,
+    //     rows dealt over the splits;  (S) the agent threads of each 64-group are ranked by list length;  (E) list
+    //     emission + the fp32 reward sums in ONE walk over the kept bits, four lanes per agent (rank ranges), sixteen agents
+    //     of SIMILAR list length per wave -- a wave loops as long as its longest range, so grouping by length is what turns
+    //     the per-wave trip count from max(n) / 4 into (roughly) the quartile's n / 4.
+    // ================================================================================================================
+    const float4 hq = hdr[at];
+    const int hb0 = __float_as_int(hq.z), hca0 = __float_as_int(hq.w);
+    const LatEnv &L = P.lat[es];
+    const u64 *rm = lrm + el * 64;
+    const short *rs = lrs + el * 64;
+    const bool flg = (sflag[at] & 1) != 0;           // a pair within 1e-9 of the "nearby" threshold: exact occupied test
+    for (int rep = 0, reps = REPS(4); rep < reps; ++rep) {
+        FENCE();
+        for (int t = sx; t < P.lat_nrs; t += WPE) {
+            const int b = hb0 + t;
+            const int bq = b < 0 ? 0 : (b > 63 ? 63 : b);
+            const unsigned sel = srow[t * AG + at];                      // empty outside the lattice / for inactive lanes
+            const u64 rowm = rm[bq];
+            const int base = rs[bq] + __popcll(rowm & ((1ull << hca0) - 1ull));   // cell index of the first set column >= ca0
+            unsigned kept = sel;
+            if (in_shape) {
+                // occupied <=> within r_avoid/2 of ANY agent: the covering agent of a SENSED cell is "nearby" (CPP:161) by
+                // the triangle inequality, except when its distance sits within rounding of the nearby threshold -- those
+                // lanes were flagged by the pair pass and are resolved with the reference's nearby x cell test.
+                const unsigned cv = (unsigned)(covrow[el * 64 + bq] >> hca0);
+                kept = sel & ~cv;
+                if (flg) {
+                    const unsigned relm = (unsigned)(rowm >> hca0);
+                    unsigned it = sel & cv;
+                    kept = sel;
+                    while (it) {
+                        const int c = __ffs(it) - 1; it &= it - 1;
+                        const double2 g = cell64(base + __popc(relm & ((1u << c) - 1u)));
+                        bool occ = false;
+                        for (int q = 0; q < NW && !occ; ++q) {
+                            u64 nbm = NW == 1 ? (nearby1 >> (NPAD < 64 ? el * NPAD : 0)) : snear[q * AG + at];
+                            while (nbm && !occ) {
+                                const int j = q * 64 + __ffsll((unsigned long long)nbm) - 1; nbm &= nbm - 1;
+                                const double ex = g.x - spx[j], ey = g.y - spy[j];
+                                occ = ex * ex + ey * ey < P.c_occ;
+                            }
+                        }
+                        if (occ) kept &= ~(1u << c);
+                    }
+                }
+            }
+            if (rep == reps - 1) srow[t * AG + at] = kept;
+            rbase[t * AG + at] = (unsigned short)base;
+            pcr[at * NRC + t] = (unsigned char)__popc(kept);
+            if (P.export_idx) orow[t * AG + at] = sel & ~kept;
+        }
+    }
+    // unused list slots read -1 (CPP:46-50): the whole list region is filled here, the emission overwrites its slots
+    {
+        uint4 *fill = reinterpret_cast<uint4 *>(sidx);
+        const int n16 = (AG * P.g_stride * 2) >> 4;
+        for (int q = tid; q < n16; q += T) fill[q] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    }
+    __syncthreads();
+    STAMP(5);
+    EXIT_AT(6);
+
+    // ---- (S) rank of every agent thread by (list length, index) inside its 64-group: each split compares against a quarter
+    // of the group (the other agents' keys come from the wave's own lanes), the partial counts are summed through LDS
+    int *prk = part_c;                                   // [WPE][AG] (the nearest-cell candidates are consumed)
+    int n_kept;
+    {
+        const uint4 cq = reinterpret_cast<const uint4 *>(pcr)[at];
+        n_kept = (int)__builtin_amdgcn_sad_u8(cq.x, 0u, __builtin_amdgcn_sad_u8(cq.y, 0u, __builtin_amdgcn_sad_u8(cq.z, 0u, __builtin_amdgcn_sad_u8(cq.w, 0u, 0u))));
+        const int key = n_kept * 64 + lane;
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cnt += (__builtin_amdgcn_readlane(key, sx * 16 + q) < key) ? 1 : 0;
+        prk[sx * AG + at] = cnt;
+    }
+    n_sel = n_kept > G ? G : n_kept;
+    __syncthreads();
+    STAMP(18);
+    EXIT_AT(7);
+    int ea;                                              // the agent thread this lane works for in (E)
+    {
+        int rank = 0;
+#pragma unroll
+        for (int s = 0; s < WPE; ++s) rank += prk[s * AG + at];
+        unsigned char *pw = perm + (tid >> 6) * 64;      // this wave's own copy: no workgroup barrier needed
+        pw[rank] = (unsigned char)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ea = (at & ~63) + pw[sx * 16 + (lane >> 2)];     // split 0 takes the sixteen shortest lists, split 3 the longest
+    }
+
+    // ---- (E) capped sensed list (CPP:236-271) + exploration-reward sums (CPP:494-551), fp32 fast path.  The kept list of
+    // an agent is cut into four contiguous RANK ranges, one per lane of its quad; each lane walks its range bit by bit
+    // through the window rows.  Per kept cell: its list slot, its cell index (row base + set columns of the row mask
+    // below it) and its reward weight psi(u), u = (distance / d_sen)^2 from the LATTICE coordinates -- |v| is invariant
+    // under the lattice's rotation, so the sums run in lattice steps and need neither the stored cells nor a list
+    // read-back.  The fp32 result only DECIDES outside a guard band; inside it the sums are redone in fp64 below.
+    for (int rep = 0, reps = REPS(11); rep < reps; ++rep) {
+        FENCE();
+        const int sub = lane & 3;
+        const float4 ha = hdr[ea];
+        const float apr = ha.x, bpr = ha.y;
+        const int ab0 = __float_as_int(ha.z), aca0 = __float_as_int(ha.w);
+        const int ael = NPAD < 64 ? (ea & 63) / NPAD : 0;
+        const LatEnv &La = P.lat[(blockIdx.x * EPB + ael) < P.n_env ? (blockIdx.x * EPB + ael) : P.n_env - 1];
+        const float Rl = La.R;                                   // d_sen in lattice steps
+        const float inv_r2 = 1.0f / (Rl * Rl);
+        const u64 *rma = lrm + ael * 64;
+        const uint4 cq = reinterpret_cast<const uint4 *>(pcr)[ea];
+        const int s0 = (int)__builtin_amdgcn_sad_u8(cq.x, 0u, 0u), s1 = (int)__builtin_amdgcn_sad_u8(cq.y, 0u, 0u);
+        const int s2 = (int)__builtin_amdgcn_sad_u8(cq.z, 0u, 0u), s3 = (int)__builtin_amdgcn_sad_u8(cq.w, 0u, 0u);
+        const int nk = s0 + s1 + s2 + s3;
+        const int per = (nk + 3) >> 2;
+        const int k0 = sub * per < nk ? sub * per : nk;
+        const int k1 = k0 + per < nk ? k0 + per : nk;
+        // the window row holding rank k0: the LAST row whose first rank is <= k0 (empty rows in front of it are skipped)
+        int t, before;
+        {
+            const int c1 = s0, c2 = s0 + s1, c3 = c2 + s2;
+            const int d = (k0 >= c1 ? 1 : 0) + (k0 >= c2 ? 1 : 0) + (k0 >= c3 ? 1 : 0);
+            before = d == 0 ? 0 : (d == 1 ? c1 : (d == 2 ? c2 : c3));
+            const unsigned wd = d == 0 ? cq.x : (d == 1 ? cq.y : (d == 2 ? cq.z : cq.w));
+            const int e1 = before + (int)(wd & 255u), e2 = e1 + (int)((wd >> 8) & 255u), e3 = e2 + (int)((wd >> 16) & 255u);
+            const int j = (k0 >= e1 ? 1 : 0) + (k0 >= e2 ? 1 : 0) + (k0 >= e3 ? 1 : 0);
+            before = j == 0 ? before : (j == 1 ? e1 : (j == 2 ? e2 : e3));
+            t = 4 * d + j;
+        }
+        const unsigned *srp = srow + t * AG + ea;
+        const unsigned short *sbp = rbase + t * AG + ea;
+        unsigned kept = k0 < k1 ? *srp : 0u;
+        {   // drop the (k0 - before) lowest set bits: position of that set bit by a binary search on popcounts
+            int pb = 0, left = k0 - before;
+#pragma unroll
+            for (int sh = 16; sh >= 1; sh >>= 1) {
+                const int c = __popc((kept >> pb) & ((1u << sh) - 1u));
+                const bool go = left >= c;
+                left -= go ? c : 0; pb += go ? sh : 0;
+            }
+            kept &= ~((1u << pb) - 1u);                              // pb <= 31: that set bit exists (k0 < k1)
+        }
+        int base = *sbp;
+        int bt = ab0 + t;
+        unsigned relm = (unsigned)(rma[bt < 0 ? 0 : (bt > 63 ? 63 : bt)] >> aca0);
+        float dbf = (float)t - bpr, db2 = dbf * dbf;
+        float n0 = 0.0f, n1 = 0.0f, dn = 0.0f;
+        short *row = sidx + (size_t)ea * P.g_stride;
+        const unsigned nm1 = (unsigned)(nk - 1);
+        // rank(q) = round(q (n-1)/(G-1)) of list slot q (CPP:241-245), see the generic path for the integer form
+        auto rank_of = [&](int q) -> int {
+            if (P.cap_int) {
+                const unsigned x = 2u * (unsigned)q * nm1 + (unsigned)(G - 1);
+                const unsigned hq_ = __umulhi(x, P.cap_magic);
+                return (int)((((x - hq_) >> 1) + hq_) >> P.cap_shift);
+            }
+            return (int)round(q * ((double)nm1 / (G - 1)));
+        };
+        auto walk_range = [&](auto capped) {
+            constexpr bool CAP = decltype(capped)::value;
+            int k = k0;
+            // capped agent (n > G, rare): `slot` = number of selected ranks below k, `nxt` = the next selected rank
+            int slot = k0, nxt = 0;
+            if constexpr (CAP) {
+                if (nk > G) {
+                    // rank(q) < k  <=>  2 q (n-1) < (2k-1)(G-1) (integer form of the rounding, G-1 odd): a ceiling division
+                    if (P.cap_int) slot = k0 > 0 ? (int)((unsigned)((2 * k0 - 1) * (G - 1) + 2 * (int)nm1 - 1) / (2u * nm1)) : 0;
+                    else { slot = 0; while (slot < G && rank_of(slot) < k0) ++slot; }
+                    slot = slot < G ? slot : G;
+                    nxt = slot < G ? rank_of(slot) : 0x7FFFFFFF;
+                }
+            }
+            while (__any(k < k1)) {
+                if (k < k1) {
+                    if (kept == 0) {                                 // next window row (more kept bits exist: k < k1 <= n)
+                        ++t; srp += AG; sbp += AG; ++bt;
+                        kept = *srp; base = *sbp;
+                        relm = (unsigned)(rma[bt < 0 ? 0 : (bt > 63 ? 63 : bt)] >> aca0);
+                        dbf += 1.0f; db2 = dbf * dbf;
+                    }
+                    if (kept != 0) {
+                        const int c = __ffs(kept) - 1;
+                        kept &= kept - 1;
+                        const int cell = base + __popc(relm & ((1u << c) - 1u));
+                        bool take = true;
+                        if constexpr (CAP) {
+                            if (nk > G) {
+                                take = k == nxt;
+                                if (take) nxt = slot + 1 < G ? rank_of(slot + 1) : 0x7FFFFFFF;
+                            }
+                        }
+                        if (take) row[slot] = (short)cell;
+                        slot += take ? 1 : 0;
+                        ++k;
+                        const float da = (float)c - apr;
+                        const float u = fmaf(da, da, db2) * inv_r2;
+                        float psi = psi_u_f32(u);
+                        if constexpr (CAP) psi = take ? psi : 0.0f;
+                        n0 = fmaf(psi, da, n0); n1 = fmaf(psi, dbf, n1); dn += psi;
+                    }
+                }
+            }
+        };
+        if (__any(nk > G)) walk_range(std::true_type{}); else walk_range(std::false_type{});
+        // the quad's partial sums -> every lane of the quad (two DPP exchanges), lane 0 of the quad decides
+        auto quad_sum = [](float v) -> float {
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+            return v;
+        };
+        n0 = quad_sum(n0); n1 = quad_sum(n1); dn = quad_sum(dn);
+        if (sub == 0) {
+            const int nsl = nk > G ? G : nk;
+            const float thr = P.rew_thr_k * Rl;                      // 0.05 in lattice steps
+            const float v0f = n0 / dn, v1f = n1 / dn;
+            const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
+            const bool uni = nsl > 0 && vf < thr;
+            const bool uns = nsl > 0 && (P.force_exact || !(dn > 1e-6f) || !(fabsf(vf - thr) > P.rew_ga_lat * (float)nsl / dn + P.rew_gb_lat));
+            rres[ea] = (unsigned char)((uni ? 1 : 0) | (uns ? 2 : 0));
+        }
+    }
+    STAMP(19);
+    __syncthreads();
+    STAMP(6);
+    EXIT_AT(9);
+    if (sx == 0) {
+        const int rr = rres[at];
+        const bool has = in_shape && n_sel > 0;
+        uniform = has && (rr & 1) != 0;
+        unsure = has && (rr & 2) != 0;
+    }
+    } else {
     // ---- occupied-cell filter, CPP:144-216: a sensed cell is occupied iff some nearby agent is within
     // r_avoid/2 of it; only agents inside the shape filter (CPP:150).  kept = in_shape ? sensed & ~occupied : sensed.
     // Common case (N <= 64, no index export, no agent flagged by the pair pass): the occupied bits of every word are
@@ -1102,8 +1341,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // partial sums; the sums are combined in split order below.
     int n_kept = 0;
     for (int w = 0; w < W; ++w) n_kept += pc[w * AG + at];
-    const int G = P.g_max;
-    const int n_sel = n_kept > G ? G : n_kept;
+    n_sel = n_kept > G ? G : n_kept;
     // (1) which RANKS of the kept list survive the cap?  rank(s) = round(s * (n-1)/(G-1)), s = 0..G-1 (CPP:241-245),
     // evaluated in a uniform slot loop (split sx takes slots sx, sx+WPE, ...) and OR-ed into a per-lane bit set.
     // With G-1 odd the value s(n-1)/(G-1) is never within 1/(2(G-1)) of a half-integer, so the reference's fp64
@@ -1282,12 +1520,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int s = 0; s < WPE; ++s) {
             n0 += rsum[(s * 3 + 0) * AG + at]; n1 += rsum[(s * 3 + 1) * AG + at]; dn += rsum[(s * 3 + 2) * AG + at];
         }
-        bool uniform = false;
         const bool has = in_shape && n_sel > 0;
         const float v0f = n0 / dn, v1f = n1 / dn;
         const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
         uniform = has && vf < 0.05f;
-        const bool unsure = has && (P.force_exact || !(dn > 1e-6f) || !(fabsf(vf - 0.05f) > P.rew_ga * (float)n_sel / dn + P.rew_gb));
+        unsure = has && (P.force_exact || !(dn > 1e-6f) || !(fabsf(vf - 0.05f) > P.rew_ga * (float)n_sel / dn + P.rew_gb));
+    }
+    }
+
+    if (sx == 0) {
+        const bool has = in_shape && n_sel > 0;
+        (void)has;
         u64 um = __ballot(unsure);
         if (um != 0) {
             const double inv_dsen = 1.0 / P.d_sen;
@@ -1298,7 +1541,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 // order of additions.  (A lane looping alone over its list made this workgroup a straggler.)
                 // scratch [3][64] doubles per wave: over the (dead) rsum for one wave per split, behind it when the other
                 // waves of this split may still be reading theirs
-                double *scr = reinterpret_cast<double *>(smem + P.off_cmask + (NW > 1 ? WPE * 3 * AG * 4 + aw * 1536 : 0));
+                // (lattice launches: over the window-row words, dead since the list phase)
+                double *scr = LAT ? reinterpret_cast<double *>(smem + P.off_srow + aw * 1536)
+                                  : reinterpret_cast<double *>(smem + P.off_cmask + (NW > 1 ? WPE * 3 * AG * 4 + aw * 1536 : 0));
                 while (um != 0) {
                     const int L = __ffsll((unsigned long long)um) - 1;               // agent thread, wave-uniform
                     um &= um - 1;
@@ -1346,21 +1591,31 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             const short *row = sidx + (size_t)at * P.g_stride;
             int *es_ = P.exp_sensed + ((size_t)e * n_a + i) * G;
             for (int q = 0; q < G; ++q) es_[q] = row[q];
-            // occupied list with its own cap, CPP:217-233
+            // occupied list with its own cap, CPP:217-233.  NWD words of occupied bits in ascending cell order: the target-cell
+            // words of the generic scan, or the window rows of the lattice path (row-major = ascending cell index)
+            const int NWD = LAT ? P.lat_nrs : W;
+            const unsigned *ob = LAT ? orow : obits;
+            int ob0 = 0, oca0 = 0;
+            if constexpr (LAT) { const float4 hq = hdr[at]; ob0 = __float_as_int(hq.z); oca0 = __float_as_int(hq.w); }
             int n_occ = 0;
-            for (int w = 0; w < W; ++w) n_occ += __popc(obits[w * AG + at]);
+            for (int w = 0; w < NWD; ++w) n_occ += __popc(ob[w * AG + at]);
             const int O = P.occ_max;
             int *eo = P.exp_occ + ((size_t)e * n_a + i) * O;
             const bool osub = n_occ > O;
             const double ostep = osub ? (double)(n_occ - 1) / (O - 1) : 0.0;
             int os = 0, ok = 0, otarget = 0;
-            for (int w = 0; w < W; ++w) {
-                unsigned it = obits[w * AG + at];
+            for (int w = 0; w < NWD; ++w) {
+                unsigned it = ob[w * AG + at];
+                int cbase = w * 32; unsigned relm = 0xFFFFFFFFu;           // generic: cell = 32 w + bit
+                if constexpr (LAT) {
+                    const int bq = ob0 + w < 0 ? 0 : (ob0 + w > 63 ? 63 : ob0 + w);
+                    cbase = rbase[w * AG + at]; relm = (unsigned)(lrm[el * 64 + bq] >> oca0);
+                }
                 while (it) {
                     const int b = __ffs(it) - 1;
                     it &= it - 1;
                     const bool sel = osub ? (ok == otarget) : true;
-                    if (sel && os < O) { eo[os++] = w * 32 + b; if (osub) otarget = (int)round(os * ostep); }
+                    if (sel && os < O) { eo[os++] = cbase + __popc(relm & ((1u << b) - 1u)); if (osub) otarget = (int)round(os * ostep); }
                     ++ok;
                 }
             }
@@ -1869,7 +2124,7 @@ struct swarm_env {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool have_cells, have_state, observed;
-    int attr_smem[6];
+    int attr_smem[12];
     std::vector<char> cells_set;
     std::string err;
     // device buffers
@@ -1994,7 +2249,7 @@ bool detect_lattice(const double *gx, const double *gy, int n, LatEnv &L)
 template <int NPAD>
 void layout_t(KP &k)
 {
-    constexpr int AG = Geo<NPAD>::AG, EPB = Geo<NPAD>::EPB, NW = Geo<NPAD>::NW, WPE = Geo<NPAD>::WPE;
+    constexpr int AG = Geo<NPAD>::AG, EPB = Geo<NPAD>::EPB, NW = Geo<NPAD>::NW, WPE = Geo<NPAD>::WPE, T = Geo<NPAD>::T;
     k.ngw = (k.ng_max + 31) / 32;
     k.cxy_stride = k.ngw * 32 + 1;            // +1 pair: envs of one wave start on different LDS banks
     int half = (k.g_max + 1) / 2;
@@ -2003,12 +2258,37 @@ void layout_t(KP &k)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~size_t(15); return (int)o; };
     auto max2 = [](size_t a, size_t b) { return a > b ? a : b; };
+    const size_t pm_bytes = (size_t)(NW == 1 ? WPE * 4 : 5) * NW * AG * 8;   // partial pair masks (per-split copies for N <= 64, one accumulator set above)
     k.off_cxy = 0;                             // fp64 cells are no longer staged in LDS
     k.off_sp = take((size_t)4 * AG * 8);
     k.cxq_stride = k.ngw * 64 + 4;             // floats: 2 per cell, +1 pair-of-pairs of padding
+    if (k.lattice) {
+        // row-space lattice path: no per-cell bit sets at all
+        constexpr int NRC = 16;
+        k.off_hdr = take((size_t)AG * 16);
+        k.off_srow = take(max2((size_t)NRC * AG * 4, (size_t)NW * 1536));   // window-row words | scratch of the exact reward
+        k.off_sbase = take((size_t)NRC * AG * 2);
+        k.off_pcr = take((size_t)AG * NRC);
+        k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, pm_bytes));      // sidx | pm
+        k.off_partc = take((size_t)WPE * AG * 4);                             // nearest-cell candidates | partial ranks
+        k.off_lat = take((size_t)EPB * 64 * (8 + 2));
+        k.off_cov = take((size_t)EPB * 64 * 8);
+        k.off_flag = take((size_t)AG * 4);
+        k.off_snei = take((size_t)AG * kNeiStride * 2);
+        k.off_sncf = take((size_t)AG * 4);
+        k.off_snear = take((size_t)NW * AG * 8);
+        k.off_perm = take((size_t)T);
+        k.off_rres = take((size_t)AG);
+        k.smem_lat = (int)off;                           // lattice mode, no export
+        k.off_orow = take((size_t)NRC * AG * 4);         // only launches that export the index scratch use it
+        k.smem_lat_export = (int)off;
+        k.off_cmask = k.off_sbits = k.off_obits = k.off_pc = k.off_cxyf = 0;     // generic scan only
+        k.smem_generic = 0;
+        return;
+    }
     k.off_cmask = take(max2(max2((size_t)k.ngw * 32 * NW * 8, (size_t)WPE * 3 * AG * 4 + (NW > 1 ? NW * 1536 : 0)), (size_t)(k.ngw + 1) * AG * 4));   // cmask | rsel | rsum
     k.off_sbits = take((size_t)(k.ngw + 1) * AG * 4);
-    k.off_sidx = take(max2(max2((size_t)AG * k.g_stride * 2, (size_t)(NW == 1 ? WPE * 4 : 5) * NW * AG * 8), (size_t)14 * AG * 8));  // sidx | pm (per-split copies for N <= 64, one accumulator set above)
+    k.off_sidx = take(max2(max2((size_t)AG * k.g_stride * 2, pm_bytes), (size_t)14 * AG * 8));
     k.off_partc = take((size_t)WPE * AG * 4);
     k.off_lat = take((size_t)EPB * 64 * (8 + 2));
     k.off_cov = take((size_t)EPB * (k.ngw + 1) * 4);
@@ -2017,11 +2297,11 @@ void layout_t(KP &k)
     k.off_sncf = take((size_t)AG * 4);
     k.off_snear = take((size_t)NW * AG * 8);
     k.off_pc = take((size_t)k.ngw * AG);
-    k.smem_lat = (int)off;                           // lattice mode, no export
-    k.off_obits = take((size_t)k.ngw * AG * 4);      // only launches that export the index scratch use it
-    k.smem_lat_export = (int)off;
-    k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);   // fp32 cell copy: the generic (non-lattice) scan only
+    k.off_obits = take((size_t)k.ngw * AG * 4);
+    k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);   // fp32 cell copy of the generic scan
     k.smem_generic = (int)off;
+    k.smem_lat = k.smem_lat_export = 0;
+    k.off_hdr = k.off_srow = k.off_sbase = k.off_pcr = k.off_perm = k.off_rres = k.off_orow = 0;
 }
 
 void layout(KP &k, int npad)
@@ -2036,16 +2316,41 @@ void layout(KP &k, int npad)
     }
 }
 
-template <int NPAD, typename OT, bool DO_STEP>
+// Decide the cell path of the next launches and lay out its LDS.  The row-space lattice path needs every env's cells to
+// be a lattice subset AND a sensing window of at most 15 lattice rows (d_sen < ~7.5 cells: a window row then has at
+// most 17 columns -- one 32-bit word -- and a list at most 240 cells -- one byte per row count); anything else takes the
+// generic scan, which handles arbitrary cell sets.
+void set_lattice_mode(swarm_env *h, bool all_lattice, float rmax, float cmax, int ncols_max)
+{
+    KP &k = h->kp;
+    k.lat_n32 = ncols_max <= 32 ? 1 : 0;
+    k.lat_rw = (int)std::ceil(rmax + 0.02f);
+    k.lat_cw = (int)std::ceil(cmax + 0.02f);
+    k.lat_nrs = (int)std::floor(2.0f * (rmax + 0.01f)) + 1; k.lat_nrc = (int)std::floor(2.0f * (cmax + 0.01f)) + 1;
+    k.lattice = (all_lattice && !h->lattice_disabled && k.lat_nrs <= 15) ? 1 : 0;
+    {   // guard band of the fp32 reward decision of the lattice path, in lattice steps (R = d_sen / l <= rmax).  Per cell the
+        // model coordinate relative to the agent is off by dx: lattice fit tolerance 1.5e-6 steps, fp32 cast of the relative
+        // coordinate (|.| <= 17 steps) and its subtraction 2.1e-6, margin: 6e-6.  As in swarm_create: psi is off by
+        // dpsi <= (pi^2 / 4) (2 sqrt(2) dx / R) + 4e-7, |v| by n (dpsi R + dx + thr dpsi) / den, thr = 0.05 R / d_sen;
+        // fp32 accumulation / division / sqrt: 4e-6 relative to d_sen, i.e. 4e-6 R / d_sen steps.  1.3x margin.
+        const double dx = 6e-6, R = std::fmax(1.0, (double)rmax), thr = 0.05 * R / k.d_sen;
+        const double dpsi_R = 2.4675 * 2.0 * std::sqrt(2.0) * dx + 4e-7 * R;        // dpsi * R
+        k.rew_ga_lat = (float)(1.3 * (dpsi_R + dx + thr * dpsi_R / R));
+        k.rew_gb_lat = (float)(4e-6 * R / k.d_sen);
+    }
+    layout(k, h->npad);
+}
+
+template <int NPAD, typename OT, bool DO_STEP, bool LAT>
 int launch_t(swarm_env *h, const void *action, int act_f64, void *obs, float *reward, uint8_t *done, void *a_prior)
 {
     constexpr int T = Geo<NPAD>::T, EPB = Geo<NPAD>::EPB;
-    auto kern = k_env<NPAD, OT, DO_STEP>;
-    int smem = !h->kp.lattice ? h->kp.smem_generic : (h->kp.export_idx ? h->kp.smem_lat_export : h->kp.smem_lat);
+    auto kern = k_env<NPAD, OT, DO_STEP, LAT>;
+    int smem = !LAT ? h->kp.smem_generic : (h->kp.export_idx ? h->kp.smem_lat_export : h->kp.smem_lat);
 #ifdef SWARM_EXTRA_SMEM
     smem += SWARM_EXTRA_SMEM;                            // occupancy experiments only
 #endif
-    int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : sizeof(OT) == 2 ? 4 : 0)];   // raise the dynamic-LDS cap once per instantiation
+    int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : sizeof(OT) == 2 ? 4 : 0) + (LAT ? 6 : 0)];   // raise the dynamic-LDS cap once per instantiation
     if (attr < smem) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = smem;
@@ -2057,19 +2362,26 @@ int launch_t(swarm_env *h, const void *action, int act_f64, void *obs, float *re
     return SWARM_OK;
 }
 
+template <int NPAD, typename OT, bool DO_STEP>
+int launch_l(swarm_env *h, const void *action, int act_f64, void *obs, float *reward, uint8_t *done, void *a_prior)
+{
+    return h->kp.lattice ? launch_t<NPAD, OT, DO_STEP, true>(h, action, act_f64, obs, reward, done, a_prior)
+                         : launch_t<NPAD, OT, DO_STEP, false>(h, action, act_f64, obs, reward, done, a_prior);
+}
+
 template <int NPAD>
 int launch_n(swarm_env *h, bool do_step, const void *action, int act_f64, void *obs, float *reward, uint8_t *done,
              void *a_prior)
 {
     const int dt = h->cfg.obs_dtype;
     if (do_step) {
-        return dt == SWARM_F64 ? launch_t<NPAD, double, true>(h, action, act_f64, obs, reward, done, a_prior)
-             : dt == SWARM_BF16 ? launch_t<NPAD, __bf16, true>(h, action, act_f64, obs, reward, done, a_prior)
-                                : launch_t<NPAD, float, true>(h, action, act_f64, obs, reward, done, a_prior);
+        return dt == SWARM_F64 ? launch_l<NPAD, double, true>(h, action, act_f64, obs, reward, done, a_prior)
+             : dt == SWARM_BF16 ? launch_l<NPAD, __bf16, true>(h, action, act_f64, obs, reward, done, a_prior)
+                                : launch_l<NPAD, float, true>(h, action, act_f64, obs, reward, done, a_prior);
     }
-    return dt == SWARM_F64 ? launch_t<NPAD, double, false>(h, action, act_f64, obs, reward, done, a_prior)
-         : dt == SWARM_BF16 ? launch_t<NPAD, __bf16, false>(h, action, act_f64, obs, reward, done, a_prior)
-                            : launch_t<NPAD, float, false>(h, action, act_f64, obs, reward, done, a_prior);
+    return dt == SWARM_F64 ? launch_l<NPAD, double, false>(h, action, act_f64, obs, reward, done, a_prior)
+         : dt == SWARM_BF16 ? launch_l<NPAD, __bf16, false>(h, action, act_f64, obs, reward, done, a_prior)
+                            : launch_l<NPAD, float, false>(h, action, act_f64, obs, reward, done, a_prior);
 }
 
 int launch(swarm_env *h, bool do_step, const void *action, int act_f64, void *obs, float *reward, uint8_t *done,
@@ -2188,6 +2500,8 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
             k.rew_ga = (float)(1.3 * (dpsi * k.d_sen + dx + 0.0505 * dpsi));
             k.rew_gb = 4e-6f;
         }
+        k.rew_thr_k = (float)(0.05 / k.d_sen);
+        k.rew_ga_lat = k.rew_gb_lat = 0.0f;
         k.force_exact = (cfg->debug_flags & 1) ? 1 : 0;
         {   // unsigned division by D = 2 (G-1) (Granlund-Montgomery round-up method, exact for every 32-bit x)
             const unsigned D = 2u * (unsigned)(k.g_max - 1);
@@ -2330,12 +2644,7 @@ int swarm_set_cells(swarm_env_t *h, int env_begin, int count, const double *cell
             rmax = std::max(rmax, h->lat_R[(size_t)e2]); cmax = std::max(cmax, h->lat_Rc[(size_t)e2]);
             ncmax = std::max(ncmax, h->lat_ncols[(size_t)e2]);
         }
-        h->kp.lattice = all ? 1 : 0;
-        h->kp.lat_n32 = ncmax <= 32 ? 1 : 0;
-        h->kp.lat_rw = (int)std::ceil(rmax + 0.02f);
-        h->kp.lat_cw = (int)std::ceil(cmax + 0.02f);
-        h->kp.lat_nrs = (int)std::floor(2.0f * (rmax + 0.01f)) + 1; h->kp.lat_nrc = (int)std::floor(2.0f * (cmax + 0.01f)) + 1;
-        if (h->kp.lat_rw > 30) h->kp.lattice = 0;           // sensing radius of > 30 cells: not worth a row walk
+        set_lattice_mode(h, all, rmax, cmax, ncmax);
     }
     for (int k = 0; k < count; ++k) h->cells_set[(size_t)(env_begin + k)] = 1;
     h->have_cells = true;
@@ -2405,12 +2714,7 @@ int swarm_reset(swarm_env_t *h, uint64_t seed, uint64_t episode, int64_t env_off
     std::fill(h->lat_R.begin(), h->lat_R.end(), h->shapes_rmax); std::fill(h->lat_Rc.begin(), h->lat_Rc.end(), h->shapes_cmax);
     std::fill(h->lat_ncols.begin(), h->lat_ncols.end(), h->shapes_ncols);
     h->have_cells = h->have_state = true;
-    h->kp.lattice = h->shapes_lattice ? 1 : 0;
-    h->kp.lat_rw = (int)std::ceil(h->shapes_rmax + 0.02f);
-    h->kp.lat_cw = (int)std::ceil(h->shapes_cmax + 0.02f);
-    h->kp.lat_nrs = (int)std::floor(2.0f * (h->shapes_rmax + 0.01f)) + 1; h->kp.lat_nrc = (int)std::floor(2.0f * (h->shapes_cmax + 0.01f)) + 1;
-    h->kp.lat_n32 = h->shapes_ncols <= 32 ? 1 : 0;
-    if (h->kp.lat_rw > 30) h->kp.lattice = 0;
+    set_lattice_mode(h, h->shapes_lattice, h->shapes_rmax, h->shapes_cmax, h->shapes_ncols);
     h->observed = false;
     return swarm_observe(h, obs);
 }
