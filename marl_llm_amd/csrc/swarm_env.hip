@@ -86,7 +86,7 @@ struct KP {
     int off_cxyf, off_partc, off_lat, off_cov, off_flag;
     // lattice (row-space) launches only: per-agent frame, per (window row, agent) column masks / first cell index, per-agent
     // row counts, the agent permutation of the list phase, the fp32 reward verdicts, the occupied columns (export only)
-    int off_hdr, off_srow, off_sbase, off_pcr, off_perm, off_rres, off_orow;
+    int off_hdr, off_srow, off_pcr, off_perm, off_rres, off_orow;
     float rew_ga_lat, rew_gb_lat;   // guard band of the fp32 reward decision in lattice steps (see swarm_create)
     float rew_thr_k;           // 0.05 / d_sen: the reward's |v| threshold in lattice steps is rew_thr_k * (d_sen / l)
     int lattice;               // every env's cells are a lattice subset whose sensing window is <= 15 rows: row-space path
@@ -283,8 +283,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // columns are stored relative to the agent's first column ca0 (<= 17 columns are ever in range: 32-bit words)
     constexpr int NRC = 16;                                              // window rows stored per agent (lat_nrs <= 15)
     float4 *hdr = reinterpret_cast<float4 *>(smem + P.off_hdr);          // [AG] {apr = a - ca0, bpr = b - b0, b0, ca0} (last two: ints)
-    unsigned *srow = reinterpret_cast<unsigned *>(smem + P.off_srow);    // [NRC][AG] sensed, then kept columns of window row t
-    unsigned short *rbase = reinterpret_cast<unsigned short *>(smem + P.off_sbase);   // [NRC][AG] cell index of column ca0 in that row
+    unsigned *srow = reinterpret_cast<unsigned *>(smem + P.off_srow);    // [NRC][AG] sensed, then kept columns of window row t (17 bits) | cell index of the row's column ca0 << 17
     unsigned char *pcr = smem + P.off_pcr;                               // [AG][NRC] kept cells per window row
     u64 *covrow = reinterpret_cast<u64 *>(smem + P.off_cov);             // [EPB][64] columns within r_avoid/2 of ANY agent, per lattice row
     unsigned char *perm = smem + P.off_perm;                             // [T/64][64] agent threads in ascending list length (per wave)
@@ -1031,7 +1030,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         for (int t = sx; t < P.lat_nrs; t += WPE) {
             const int b = hb0 + t;
             const int bq = b < 0 ? 0 : (b > 63 ? 63 : b);
-            const unsigned sel = srow[t * AG + at];                      // empty outside the lattice / for inactive lanes
+            const unsigned sel = srow[t * AG + at] & 0x1FFFFu;           // empty outside the lattice / for inactive lanes (the mask: REPS reruns)
             const u64 rowm = rm[bq];
             const int base = rs[bq] + __popcll(rowm & ((1ull << hca0) - 1ull));   // cell index of the first set column >= ca0
             unsigned kept = sel;
@@ -1061,8 +1060,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     }
                 }
             }
-            if (rep == reps - 1) srow[t * AG + at] = kept;
-            rbase[t * AG + at] = (unsigned short)base;
+            if (rep == reps - 1) srow[t * AG + at] = kept | ((unsigned)base << 17);     // <= 17 window columns, cell index < 2^15
             pcr[at * NRC + t] = (unsigned char)__popc(kept);
             if (P.export_idx) orow[t * AG + at] = sel & ~kept;
         }
@@ -1122,7 +1120,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int ael = NPAD < 64 ? (ea & 63) / NPAD : 0;
         const LatEnv &La = P.lat[(blockIdx.x * EPB + ael) < P.n_env ? (blockIdx.x * EPB + ael) : P.n_env - 1];
         const float Rl = La.R;                                   // d_sen in lattice steps
-        const float inv_r2 = 1.0f / (Rl * Rl);
+        const float inv_r2 = __builtin_amdgcn_rcpf(Rl * Rl);       // 1 ulp: inside the guard band's allowance for psi
         const u64 *rma = lrm + ael * 64;
         const uint4 cq = reinterpret_cast<const uint4 *>(pcr)[ea];
         const int s0 = (int)__builtin_amdgcn_sad_u8(cq.x, 0u, 0u), s1 = (int)__builtin_amdgcn_sad_u8(cq.y, 0u, 0u);
@@ -1143,9 +1141,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             before = j == 0 ? before : (j == 1 ? e1 : (j == 2 ? e2 : e3));
             t = 4 * d + j;
         }
-        const unsigned *srp = srow + t * AG + ea;
-        const unsigned short *sbp = rbase + t * AG + ea;
-        unsigned kept = k0 < k1 ? *srp : 0u;
+        const unsigned *srp = srow + t * AG + ea;                    // kept columns (17 bits) | first cell index of the row << 17
+        const unsigned wd0 = *srp;
+        unsigned kept = k0 < k1 ? (wd0 & 0x1FFFFu) : 0u;
         {   // drop the (k0 - before) lowest set bits: position of that set bit by a binary search on popcounts
             int pb = 0, left = k0 - before;
 #pragma unroll
@@ -1156,9 +1154,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
             kept &= ~((1u << pb) - 1u);                              // pb <= 31: that set bit exists (k0 < k1)
         }
-        int base = *sbp;
-        int bt = ab0 + t;
-        unsigned relm = (unsigned)(rma[bt < 0 ? 0 : (bt > 63 ? 63 : bt)] >> aca0);
+        int base = (int)(wd0 >> 17);
+        // a lane with k0 < k1 only ever visits rows between two non-empty window rows -- rows of the lattice, 0 <= b < 64 --
+        // so the walk needs no range check on the row; the first read of a lane without work is clamped
+        const int bt0 = ab0 + t;
+        const u64 *rmp = rma + (bt0 < 0 ? 0 : (bt0 > 63 ? 63 : bt0));
+        unsigned relm = (unsigned)(*rmp >> aca0);
         float dbf = (float)t - bpr, db2 = dbf * dbf;
         float n0 = 0.0f, n1 = 0.0f, dn = 0.0f;
         short *row = sidx + (size_t)ea * P.g_stride;
@@ -1189,9 +1190,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             while (__any(k < k1)) {
                 if (k < k1) {
                     if (kept == 0) {                                 // next window row (more kept bits exist: k < k1 <= n)
-                        ++t; srp += AG; sbp += AG; ++bt;
-                        kept = *srp; base = *sbp;
-                        relm = (unsigned)(rma[bt < 0 ? 0 : (bt > 63 ? 63 : bt)] >> aca0);
+                        srp += AG; ++rmp;
+                        const unsigned wd = *srp;
+                        kept = wd & 0x1FFFFu; base = (int)(wd >> 17);
+                        relm = (unsigned)(*rmp >> aca0);
                         dbf += 1.0f; db2 = dbf * dbf;
                     }
                     if (kept != 0) {
@@ -1205,8 +1207,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                                 if (take) nxt = slot + 1 < G ? rank_of(slot + 1) : 0x7FFFFFFF;
                             }
                         }
-                        if (take) row[slot] = (short)cell;
-                        slot += take ? 1 : 0;
+                        if constexpr (CAP) { if (take) row[slot] = (short)cell; slot += take ? 1 : 0; }
+                        else row[k] = (short)cell;                   // under the cap the slot of a cell is its rank
                         ++k;
                         const float da = (float)c - apr;
                         const float u = fmaf(da, da, db2) * inv_r2;
@@ -1609,7 +1611,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 int cbase = w * 32; unsigned relm = 0xFFFFFFFFu;           // generic: cell = 32 w + bit
                 if constexpr (LAT) {
                     const int bq = ob0 + w < 0 ? 0 : (ob0 + w > 63 ? 63 : ob0 + w);
-                    cbase = rbase[w * AG + at]; relm = (unsigned)(lrm[el * 64 + bq] >> oca0);
+                    const u64 rowm = lrm[el * 64 + bq];
+                    cbase = lrs[el * 64 + bq] + __popcll(rowm & ((1ull << oca0) - 1ull)); relm = (unsigned)(rowm >> oca0);
                 }
                 while (it) {
                     const int b = __ffs(it) - 1;
@@ -2267,7 +2270,6 @@ void layout_t(KP &k)
         constexpr int NRC = 16;
         k.off_hdr = take((size_t)AG * 16);
         k.off_srow = take(max2((size_t)NRC * AG * 4, (size_t)NW * 1536));   // window-row words | scratch of the exact reward
-        k.off_sbase = take((size_t)NRC * AG * 2);
         k.off_pcr = take((size_t)AG * NRC);
         k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, pm_bytes));      // sidx | pm
         k.off_partc = take((size_t)WPE * AG * 4);                             // nearest-cell candidates | partial ranks
@@ -2301,7 +2303,7 @@ void layout_t(KP &k)
     k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);   // fp32 cell copy of the generic scan
     k.smem_generic = (int)off;
     k.smem_lat = k.smem_lat_export = 0;
-    k.off_hdr = k.off_srow = k.off_sbase = k.off_pcr = k.off_perm = k.off_rres = k.off_orow = 0;
+    k.off_hdr = k.off_srow = k.off_pcr = k.off_perm = k.off_rres = k.off_orow = 0;
 }
 
 void layout(KP &k, int npad)
@@ -2334,7 +2336,7 @@ void set_lattice_mode(swarm_env *h, bool all_lattice, float rmax, float cmax, in
         // dpsi <= (pi^2 / 4) (2 sqrt(2) dx / R) + 4e-7, |v| by n (dpsi R + dx + thr dpsi) / den, thr = 0.05 R / d_sen;
         // fp32 accumulation / division / sqrt: 4e-6 relative to d_sen, i.e. 4e-6 R / d_sen steps.  1.3x margin.
         const double dx = 6e-6, R = std::fmax(1.0, (double)rmax), thr = 0.05 * R / k.d_sen;
-        const double dpsi_R = 2.4675 * 2.0 * std::sqrt(2.0) * dx + 4e-7 * R;        // dpsi * R
+        const double dpsi_R = 2.4675 * 2.0 * std::sqrt(2.0) * dx + 8e-7 * R;        // dpsi * R (8e-7: polynomial 4e-7 + the 1-ulp reciprocal of R^2)
         k.rew_ga_lat = (float)(1.3 * (dpsi_R + dx + thr * dpsi_R / R));
         k.rew_gb_lat = (float)(4e-6 * R / k.d_sen);
     }

@@ -17,6 +17,11 @@ NAMES = ["forces+prior+integrate", "pair masks", "cell scan", "occupied filter",
          "obs head pairs", "obs sensed pairs", "cell staging", "ordered insertion", "emit walk", "nearest merge"]
 
 
+SEGS = [(0, "loads+first barrier"), (1, "forces+integrate"), (2, "pair masks"), (3, "ordered insertion"), (4, "cell walk"),
+        (5, "nearest merge"), (6, "kept rows + counts"), (7, "rank by list length"), (9, "emit + reward sums"),
+        (10, "reward combine"), (11, "obs head pairs"), (None, "obs sensed pairs (full kernel)")]
+
+
 def run(skip, n_a, E, sy, ra, state, steps=int(os.environ.get('ABLATE_STEPS', '60'))):
     sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra, debug_flags=skip)
     sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"])
@@ -55,12 +60,10 @@ def main():
         return
     if "--cumulative" in sys.argv:
         # leave the kernel after segment k (debug phase 15): cumulative time / counters up to each point
-        segs = ["loads+first barrier", "forces+prior+integrate", "pair masks", "ordered insertion", "cell walk",
-                "nearest merge", "occupied filter", "rank-select", "emit", "reward sums", "reward combine",
-                "obs head pairs", "obs sensed pairs (full kernel)"]
+        # (exit code, label): the lattice (row-space) kernel has no separate rank-select / reward-sum segments
         prev = 0.0
-        for k, nm in enumerate(segs):
-            ms = run((15 << 8) | (k << 12), n_a, E, sy, ra, state) if k < 12 else run(0, n_a, E, sy, ra, state)
+        for code, nm in SEGS:
+            ms = run((15 << 8) | (code << 12), n_a, E, sy, ra, state) if code is not None else run(0, n_a, E, sy, ra, state)
             print(f"  exit after {nm:32s} {ms * 1e3:8.1f} us   (+{(ms - prev) * 1e3:6.1f})")
             prev = ms
         return

@@ -8,11 +8,14 @@ Collect (GPU box; variable exported in the calling shell, python3 directly after
 """
 import collections, csv, sys
 path, k = sys.argv[1], int(sys.argv[2])
-segs = ["loads+first barrier", "forces+prior+integrate", "pair masks", "ordered insertion", "cell walk", "nearest merge",
-        "occupied filter", "rank-select", "emit", "reward sums", "reward combine", "obs head pairs", "obs sensed pairs (full)"]
+import os, re
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ablate import SEGS
+segs = [nm for _, nm in SEGS]
+STEP = re.compile(r"k_env<\s*\d+,\s*[\w ]+,\s*true\s*,")     # k_env<N, dtype, DO_STEP = true, LAT>
 rows = collections.defaultdict(list)
 for r in csv.DictReader(open(path)):
-    if "k_env<" in r["Kernel_Name"] and "true>" in r["Kernel_Name"]:
+    if STEP.search(r["Kernel_Name"]):
         rows[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for cname, v in rows.items():
     v.sort()

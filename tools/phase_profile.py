@@ -20,11 +20,12 @@ from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
 from marl_llm_amd.synth import synthetic_batch
 
 # stamp ids in program order and what ENDS at each of them
+# (lattice / row-space kernel: the synthetic and the reference's shapes; the generic scan keeps the round-2 stamp points)
 ORDER = [(0, "start"), (1, "prologue loads + barrier"), (2, "forces | prior, integrate, 2 barriers"),
          (14, "pair-mask loop"), (15, "pair masks: LDS exchange + barrier"), (3, "ordered insertion (B only)"),
          (16, "lattice walk (not B)"), (17, "barrier after walk"), (4, "nearest merge (gathers)"),
-         (5, "occupied filter + barrier"), (18, "rank-select + barrier"), (19, "list emission"),
-         (20, "barrier after emission"), (21, "reward sums (gathers)"), (6, "barrier after reward sums"),
+         (5, "kept rows + counts + list fill + barrier"), (18, "rank by list length + barrier"),
+         (19, "list emission + reward sums (quads)"), (6, "barrier after emission"),
          (22, "reward combine + stores (A only)"), (9, "obs head pairs"), (7, "obs sensed pairs")]
 
 

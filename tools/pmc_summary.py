@@ -8,11 +8,13 @@ import csv
 import json
 import sys
 
+import re
+STEP = re.compile(r"k_env<\s*\d+,\s*[\w ]+,\s*true\s*,")     # k_env<N, dtype, DO_STEP = true, LAT>: the step launches
 out, last_n, workload = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 vals = collections.defaultdict(list)
 for path in sys.argv[4:]:
     for r in csv.DictReader(open(path)):
-        if "k_env<" in r["Kernel_Name"] and "true>" in r["Kernel_Name"]:
+        if STEP.search(r["Kernel_Name"]):
             vals[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 res = {}
 for k, v in sorted(vals.items()):
