@@ -520,35 +520,46 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         // One compare + one add-with-carry per test: the compare's lane mask is the carry-in of acc = 2 acc + carry, so
         // after the JQ agents of this split bit (JQ-1-q) of acc is the answer for agent q; reversed and shifted into
         // place (agent j = sx*JQ + q) at the end.
-        unsigned a_nb[NW], a_cd[NW], a_c1[NW], a_ht[NW], a_c2[NW];
+        unsigned a_nb[1], a_cd[1], a_c1[1], a_ht[1];       // N <= 64: this split's partial masks (N > 64 ORs each group into LDS at once)
         bool exc = false;
+        auto place = [&](unsigned acc) -> u64 { return (u64)(__brev(acc) >> (32 - JQ)) << (sx * JQ); };
         for (int rep = 0, reps = REPS(2); rep < reps; ++rep) {
             FENCE();
             exc = false;
-#pragma unroll
+            // (N > 64: the loop over the 64-agent groups stays rolled -- unrolled, the pair pass alone was 20 KB of a kernel
+            // that has to fit a 64 KB instruction cache)
+#pragma unroll (NW == 1 ? 2 : 1)
             for (int w = 0; w < NW; ++w) {
-                a_nb[w] = 0; a_cd[w] = 0; a_c1[w] = 0; a_ht[w] = 0; a_c2[w] = 0;
-                unsigned a_hi = 0;
+                unsigned nb = 0, cd = 0, c1 = 0, ht = 0, c2 = 0, a_hi = 0;
+                const double *qx = spx + w * 64 + sx * JQ, *qy = spy + w * 64 + sx * JQ;
 #pragma unroll
                 for (int q = 0; q < JQ; ++q) {
-                    const int jj = sx * JQ + q;
-                    double rx = spx[w * 64 + jj] - px, ry = spy[w * 64 + jj] - py;
+                    double rx = qx[q] - px, ry = qy[q] - py;
                     const double d2u = rx * rx + ry * ry;
-                    a_nb[w] = shl1_or_mask(a_nb[w], __ballot(d2u < P.c_near));
+                    nb = shl1_or_mask(nb, __ballot(d2u < P.c_near));
                     a_hi = shl1_or_mask(a_hi, __ballot(d2u < P.c_near_hi));
-                    a_ht[w] = shl1_or_mask(a_ht[w], __ballot(d2u < P.c_ball));                        // contact pairs of the NEXT step (ENV:442-457)
+                    ht = shl1_or_mask(ht, __ballot(d2u < P.c_ball));                                  // contact pairs of the NEXT step (ENV:442-457)
                     double d2 = d2u;
                     if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                    a_cd[w] = shl1_or_mask(a_cd[w], __ballot(d2 < P.c_sen));
-                    a_c1[w] = shl1_or_mask(a_c1[w], __ballot(d2 < P.c_close));
-                    if constexpr (NW > 2) a_c2[w] = shl1_or_mask(a_c2[w], __ballot(d2 < P.c_close2));   // wider pre-selection ring (N > 128: pays there)
+                    cd = shl1_or_mask(cd, __ballot(d2 < P.c_sen));
+                    c1 = shl1_or_mask(c1, __ballot(d2 < P.c_close));
+                    if constexpr (NW > 2) c2 = shl1_or_mask(c2, __ballot(d2 < P.c_close2));           // wider pre-selection ring (N > 128: pays there)
                 }
-                exc = exc || (a_hi != a_nb[w]);        // some agent is not "nearby" by a hair (see the occupied-cell filter)
+                exc = exc || (a_hi != nb);             // some agent is not "nearby" by a hair (see the occupied-cell filter)
+                if constexpr (NW == 1) { a_nb[0] = nb; a_cd[0] = cd; a_c1[0] = c1; a_ht[0] = ht; }
+                else if (rep == reps - 1) {
+                    // N > 64: per-split copies of the masks would not fit beside the rest; the splits OR their parts into ONE
+                    // set of accumulators (zeroed in the prologue) with LDS atomics
+                    atomicOr(&pm[(0 * NW + w) * AG + at], place(nb));
+                    atomicOr(&pm[(1 * NW + w) * AG + at], place(cd));
+                    atomicOr(&pm[(2 * NW + w) * AG + at], place(c1));
+                    atomicOr(&pm[(3 * NW + w) * AG + at], place(ht));
+                    atomicOr(&pm[(4 * NW + w) * AG + at], place(c2));
+                }
             }
         }
         STAMP(14);
         if (use_lat && exc) atomicOr(&sflag[at], 1);   // resolve the occupied-cell filter of this agent exactly
-        auto place = [&](unsigned acc) -> u64 { return (u64)(__brev(acc) >> (32 - JQ)) << (sx * JQ); };
         if constexpr (NW == 1) {
             // N <= 64: every split stores its partial masks, the readers OR the WPE copies
 #pragma unroll
@@ -575,16 +586,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 P.hit[(size_t)e * n_a + i] = hh & ~(1ull << i);               // k != i
             }
         } else {
-            // N > 64: per-split copies of 4 masks x NW groups would not fit beside the rest; the splits OR their parts
-            // into ONE set of accumulators (zeroed in the prologue) with LDS atomics
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                atomicOr(&pm[(0 * NW + w) * AG + at], place(a_nb[w]));
-                atomicOr(&pm[(1 * NW + w) * AG + at], place(a_cd[w]));
-                atomicOr(&pm[(2 * NW + w) * AG + at], place(a_c1[w]));
-                atomicOr(&pm[(3 * NW + w) * AG + at], place(a_ht[w]));
-                atomicOr(&pm[(4 * NW + w) * AG + at], place(a_c2[w]));
-            }
             __syncthreads();
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -2389,14 +2390,15 @@ int launch_n(swarm_env *h, bool do_step, const void *action, int act_f64, void *
 int launch(swarm_env *h, bool do_step, const void *action, int act_f64, void *obs, float *reward, uint8_t *done,
            void *a_prior)
 {
+    // (SWARM_ONLY_NPAD: development builds with a single instantiation -- quick register / code-size checks and A/B runs)
+#ifndef SWARM_ONLY_NPAD
+#define SWARM_ONLY_NPAD 0
+#endif
+#define SWARM_CASE(n) case n: if (SWARM_ONLY_NPAD == 0 || SWARM_ONLY_NPAD == n) return launch_n<(SWARM_ONLY_NPAD == 0 || SWARM_ONLY_NPAD == n) ? n : (SWARM_ONLY_NPAD)>(h, do_step, action, act_f64, obs, reward, done, a_prior); break
     switch (h->npad) {
-    case 8: return launch_n<8>(h, do_step, action, act_f64, obs, reward, done, a_prior);
-    case 16: return launch_n<16>(h, do_step, action, act_f64, obs, reward, done, a_prior);
-    case 32: return launch_n<32>(h, do_step, action, act_f64, obs, reward, done, a_prior);
-    case 64: return launch_n<64>(h, do_step, action, act_f64, obs, reward, done, a_prior);
-    case 128: return launch_n<128>(h, do_step, action, act_f64, obs, reward, done, a_prior);
-    case 256: return launch_n<256>(h, do_step, action, act_f64, obs, reward, done, a_prior);
+    SWARM_CASE(8); SWARM_CASE(16); SWARM_CASE(32); SWARM_CASE(64); SWARM_CASE(128); SWARM_CASE(256);
     }
+#undef SWARM_CASE
     return fail(h, SWARM_ERR_INVALID, "unsupported agent count");
 }
 
