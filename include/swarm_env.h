@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SWARM_ABI_VERSION 3
+#define SWARM_ABI_VERSION 4
 
 enum { SWARM_F32 = 0, SWARM_F64 = 1, SWARM_BF16 = 2 };
 
@@ -96,6 +96,11 @@ typedef struct swarm_config {
     double vel_max;                 /* assembly.py:52   = 0.8 */
     double dt;                      /* assembly.py:79   = 0.1 */
     double boundary[4];             /* [x_min, y_max, x_max, y_min], assembly.py:193-196 */
+    double prior_gain[3];           /* prior policy gains: attraction, repulsion, alignment -- AssemblyEnv.cpp:1128-1132 = 2, 3, 2 */
+    double llm_repulsion;           /* repulsion gain of the prior's Python twin robot_prior_policy, assembly.py:895 = 1.0 */
+    int32_t llm_action;             /* 1: agent_strategy == 'llm' (assembly.py:525-529): every pass also evaluates that twin on
+                                     * the new state; swarm_step(action = NULL) then applies it as the action */
+    int32_t reserved_;
 } swarm_config_t;
 
 int  swarm_abi_version(void);
@@ -136,8 +141,34 @@ int  swarm_observe(swarm_env_t *h, void *obs);
 
 /* One AssemblySwarmEnv.step(a) for every env.  action_dtype: SWARM_F32 / SWARM_F64.
  * reward / done / a_prior may be NULL (not written). */
+/* action == NULL (handles created with llm_action only): apply the 'llm' strategy's action of the current state. */
 int  swarm_step(swarm_env_t *h, const void *action, int action_dtype,
                 void *obs, float *reward, uint8_t *done, void *a_prior);
+
+/* ---- reference-shaped HOST outputs: the numpy API of AssemblySwarmEnv.step / reset (assembly.py:487-666,156-223) ----
+ * The reference returns obs (D, n_a) float64, reward (1, n_a) float64, done (1, n_a) bool, a_prior (2, n_a) float64
+ * (assembly.py:227-231,353,480-482,612,663-666).  With E environments the agent axis is n_a = E*N, env-major.  The library
+ * owns the step outputs on the device, widens / transposes them into that layout on the device and moves them with ONE
+ * asynchronous copy into pinned host memory it owns: two slots (ping-pong; the arrays of the previous step stay valid while
+ * the next one is taken).  swarm_host_outputs returns the four host arrays of a slot (valid until swarm_destroy);
+ * a_prior is meaningful only with with_prior.  Both calls below return after the data has landed in the slot. */
+typedef struct swarm_host_out {
+    double  *obs;        /* (D, E*N)  row-major: obs[r * E*N + e*N + i] */
+    double  *a_prior;    /* (2, E*N) */
+    double  *reward;     /* (1, E*N) */
+    uint8_t *done;       /* (1, E*N)  0 / 1 */
+} swarm_host_out_t;
+int  swarm_host_outputs(swarm_env_t *h, int slot, swarm_host_out_t *out);
+/* swarm_observe + export of obs into `slot` (the tail of reset(), assembly.py:221-223). */
+int  swarm_observe_host(swarm_env_t *h, int slot);
+/* One step + export into `slot`.  action: action_on_device == 0: HOST array in the reference's layout (2, E*N)
+ * (component-major, envs side by side), float or double; action_on_device == 1: DEVICE [E][N][2] as swarm_step;
+ * NULL: the 'llm' strategy's own action (llm_action handles only). */
+int  swarm_step_host(swarm_env_t *h, const void *action, int action_dtype, int action_on_device, int slot);
+
+/* The 'llm' strategy's action for the CURRENT state (what swarm_step(action = NULL) would apply): [E][N][2] doubles, host or
+ * device pointer.  llm_action handles only. */
+int  swarm_get_llm_action(swarm_env_t *h, double *action);
 
 /* Evaluation metrics of the current state, per env: out[E][3] (DEVICE pointer, double) =
  * [coverage_rate, distribution_uniformity, voronoi_based_uniformity] of

@@ -16,7 +16,14 @@ class SwarmConfig(ctypes.Structure):
                 ("device", ctypes.c_int32), ("debug_flags", ctypes.c_int32),
                 ("d_sen", ctypes.c_double), ("r_avoid", ctypes.c_double), ("size_a", ctypes.c_double),
                 ("k_ball", ctypes.c_double), ("k_wall", ctypes.c_double), ("c_wall", ctypes.c_double),
-                ("vel_max", ctypes.c_double), ("dt", ctypes.c_double), ("boundary", ctypes.c_double * 4)]
+                ("vel_max", ctypes.c_double), ("dt", ctypes.c_double), ("boundary", ctypes.c_double * 4),
+                ("prior_gain", ctypes.c_double * 3), ("llm_repulsion", ctypes.c_double),
+                ("llm_action", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+
+
+class HostOut(ctypes.Structure):                # include/swarm_env.h swarm_host_out_t
+    _fields_ = [("obs", ctypes.POINTER(ctypes.c_double)), ("a_prior", ctypes.POINTER(ctypes.c_double)),
+                ("reward", ctypes.POINTER(ctypes.c_double)), ("done", ctypes.POINTER(ctypes.c_uint8))]
 
 
 class SwarmError(RuntimeError):
@@ -25,11 +32,12 @@ class SwarmError(RuntimeError):
 
 _LIB = None
 
-ABI_VERSION = 3            # include/swarm_env.h SWARM_ABI_VERSION
+ABI_VERSION = 4            # include/swarm_env.h SWARM_ABI_VERSION
 BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", "swarm_destroy", "swarm_last_error",
                    "swarm_set_stream", "swarm_synchronize", "swarm_obs_dim", "swarm_set_cells", "swarm_set_state",
                    "swarm_get_state", "swarm_observe", "swarm_step", "swarm_get_indices",
-                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_get_shape_index", "swarm_metrics", "swarm_rule_action")
+                   "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_get_shape_index", "swarm_metrics", "swarm_rule_action",
+                   "swarm_host_outputs", "swarm_observe_host", "swarm_step_host", "swarm_get_llm_action")
 POLICY_SYMBOLS = ("swarm_policy_create", "swarm_policy_destroy", "swarm_policy_forward", "swarm_policy_forward_bf16", "swarm_policy_last_error")   # include/swarm_policy.h
 LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior",
                   "swarm_legacy_status", "swarm_legacy_last_error")
@@ -75,6 +83,10 @@ def load():
     lib.swarm_lattice_envs.argtypes = [vp]; lib.swarm_lattice_envs.restype = i32
     lib.swarm_set_shapes.argtypes = [vp, i32, vp, vp, vp]; lib.swarm_set_shapes.restype = i32
     lib.swarm_reset.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, vp]; lib.swarm_reset.restype = i32
+    lib.swarm_host_outputs.argtypes = [vp, i32, ctypes.POINTER(HostOut)]; lib.swarm_host_outputs.restype = i32
+    lib.swarm_observe_host.argtypes = [vp, i32]; lib.swarm_observe_host.restype = i32
+    lib.swarm_step_host.argtypes = [vp, vp, i32, i32, i32]; lib.swarm_step_host.restype = i32
+    lib.swarm_get_llm_action.argtypes = [vp, vp]; lib.swarm_get_llm_action.restype = i32
     lib.swarm_timer_start.argtypes = [vp]; lib.swarm_timer_start.restype = i32
     lib.swarm_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]; lib.swarm_timer_stop.restype = i32
     if lib.swarm_abi_version() != ABI_VERSION:

@@ -20,7 +20,7 @@ class SwarmBatch:
     def __init__(self, n_env, n_agents, n_cells_max, r_avoid, *, is_boundary=True, with_self=True, with_prior=True,
                  obs_dtype=torch.float32, device="cuda:0", d_sen=0.4, topo=6, g_max=80, occ_max=200,
                  boundary=(-2.4, 2.4, 2.4, -2.4), size_a=0.035, k_ball=30.0, k_wall=100.0, c_wall=5.0,
-                 vel_max=0.8, dt=0.1, debug_flags=0):
+                 vel_max=0.8, dt=0.1, debug_flags=0, llm_action=False, prior_gain=(2.0, 3.0, 2.0), llm_repulsion=1.0):
         if not torch.cuda.is_available():
             raise SwarmError("no HIP device visible to PyTorch: the env step has no CPU fallback")
         self.lib = _lib.load()
@@ -43,6 +43,11 @@ class SwarmBatch:
         cfg.k_ball, cfg.k_wall, cfg.c_wall, cfg.vel_max, cfg.dt = float(k_ball), float(k_wall), float(c_wall), float(vel_max), float(dt)
         for k in range(4):
             cfg.boundary[k] = float(boundary[k])
+        for k in range(3):
+            cfg.prior_gain[k] = float(prior_gain[k])
+        cfg.llm_repulsion, cfg.llm_action = float(llm_repulsion), int(bool(llm_action))
+        self.has_llm_action = bool(llm_action)
+        self._host = None
         self.cfg = cfg
         self.handle = ctypes.c_void_p()
         rc = self.lib.swarm_create(ctypes.byref(cfg), ctypes.byref(self.handle))
@@ -173,21 +178,86 @@ class SwarmBatch:
     def step(self, action):
         """action [E, N, 2] float32/float64 device tensor -> (obs [E,N,D], reward [E,N], done [E,N] uint8,
         a_prior [E,N,2] or None).  Asynchronous on torch's current stream."""
-        if not isinstance(action, torch.Tensor) or action.device != self.device:
-            raise SwarmError("action must be a torch tensor on the env's device")
-        if tuple(action.shape) != (self.n_env, self.n_agents, 2):
-            raise SwarmError(f"action must be [{self.n_env}, {self.n_agents}, 2]")
-        if action.dtype not in (torch.float32, torch.float64):
-            action = action.to(torch.float32)
-        action = action.contiguous()
+        if action is None:
+            if not self.has_llm_action:
+                raise SwarmError("action=None needs a batch created with llm_action=True (agent_strategy 'llm')")
+        else:
+            if not isinstance(action, torch.Tensor) or action.device != self.device:
+                raise SwarmError("action must be a torch tensor on the env's device")
+            if tuple(action.shape) != (self.n_env, self.n_agents, 2):
+                raise SwarmError(f"action must be [{self.n_env}, {self.n_agents}, 2]")
+            if action.dtype not in (torch.float32, torch.float64):
+                action = action.to(torch.float32)
+            action = action.contiguous()
         self._flip ^= 1
         f = self._flip
         self._sync_stream()
         check(self.lib, self.handle,
-              self.lib.swarm_step(self.handle, _ptr(action), F64 if action.dtype == torch.float64 else F32,
+              self.lib.swarm_step(self.handle, _ptr(action), F64 if (action is None or action.dtype == torch.float64) else F32,
                                   _ptr(self._obs[f]), _ptr(self._rew[f]), _ptr(self._done),
                                   _ptr(self._pri[f]) if self.with_prior else None))
         return self._obs[f], self._rew[f], self._done, (self._pri[f] if self.with_prior else None)
+
+    # -- the reference-shaped host outputs (numpy API) -----------------------------------------------------
+    def host_views(self):
+        """Numpy views of the library's two pinned output slots, in the reference's layouts: per slot a dict obs (D, E*N)
+        f64, a_prior (2, E*N) f64, reward (1, E*N) f64, done (1, E*N) bool.  Created once; the arrays are rewritten in
+        place by step_host / observe_host (ping-pong: a slot is reused every second call)."""
+        if self._host is None:
+            from ._lib import HostOut
+            EN, D = self.n_env * self.n_agents, self.obs_dim
+            slots = []
+            for s in (0, 1):
+                o = HostOut()
+                check(self.lib, self.handle, self.lib.swarm_host_outputs(self.handle, s, ctypes.byref(o)))
+                slots.append(dict(obs=np.ctypeslib.as_array(o.obs, shape=(D, EN)),
+                                  a_prior=np.ctypeslib.as_array(o.a_prior, shape=(2, EN)),
+                                  reward=np.ctypeslib.as_array(o.reward, shape=(1, EN)),
+                                  done=np.ctypeslib.as_array(o.done, shape=(1, EN)).view(np.bool_)))
+            self._host = slots
+            self._hslot = 0
+        return self._host
+
+    def observe_host(self):
+        """swarm_observe + obs in the reference's (D, E*N) float64 host layout (a view of a pinned slot)."""
+        h = self.host_views()
+        self._hslot ^= 1
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_observe_host(self.handle, self._hslot))
+        return h[self._hslot]["obs"]
+
+    def step_host(self, action):
+        """One step through the host boundary.  action: numpy (2, E*N) float32/float64 in the reference's layout, a device
+        tensor [E, N, 2], or None (llm_action batches).  Returns the slot dict of host_views()."""
+        h = self.host_views()
+        self._hslot ^= 1
+        self._sync_stream()
+        if action is None:
+            rc = self.lib.swarm_step_host(self.handle, None, F64, 0, self._hslot)
+        elif isinstance(action, torch.Tensor):
+            if action.device != self.device or tuple(action.shape) != (self.n_env, self.n_agents, 2):
+                raise SwarmError("device action must be [E, N, 2] on the env's device")
+            if action.dtype not in (torch.float32, torch.float64):
+                action = action.to(torch.float32)
+            action = action.contiguous()
+            rc = self.lib.swarm_step_host(self.handle, _ptr(action), F64 if action.dtype == torch.float64 else F32, 1, self._hslot)
+        else:
+            a = np.ascontiguousarray(action)
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64)
+            if a.shape != (2, self.n_env * self.n_agents):
+                raise SwarmError("host action must be (2, %d)" % (self.n_env * self.n_agents))
+            rc = self.lib.swarm_step_host(self.handle, a.ctypes.data_as(ctypes.c_void_p), F64 if a.dtype == np.float64 else F32, 0,
+                                          self._hslot)
+        check(self.lib, self.handle, rc)
+        return h[self._hslot]
+
+    def llm_action(self):
+        """[E, N, 2] float64 device tensor: the 'llm' strategy's action for the current state (assembly.py:525-529)."""
+        out = torch.empty((self.n_env, self.n_agents, 2), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        check(self.lib, self.handle, self.lib.swarm_get_llm_action(self.handle, _ptr(out)))
+        return out
 
     def indices(self, sensed=True, occupied=True):
         """The reference's index scratch for the current state (debug / parity export)."""

@@ -106,6 +106,10 @@ struct KP {
     const double *c_in;
     int *exp_sensed, *exp_occ;
     void *prior_next;          // [E][N] pairs of the handle's obs dtype: the prior policy of the next step (written by every pass)
+    double pk_att, pk_rep, pk_ali;   // gains of the prior policy: attraction, repulsion, alignment (CPP:1128-1132: 2, 3, 2)
+    double pk_llm;             // repulsion gain of the Python twin that drives agent_strategy == 'llm' (ENV:895: 1.0)
+    int llm;                   // also evaluate that twin and leave it in act_next as the NEXT step's action (ENV:525-529)
+    double2 *act_next;         // [E][N]
     long long *stamps;         // diagnostic build only (-DSWARM_STAMPS): per-block phase clocks
 };
 
@@ -349,7 +353,14 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
         vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
         if (DO_STEP) {
-            if (act_f64) { const size_t ab = ((size_t)e * n_a + i) * 2; ax = ((const double *)action)[ab]; ay = ((const double *)action)[ab + 1]; }
+            // act_f64 bit 0: doubles; bit 1: the reference's (2, n_a) component-major layout with the envs side by side on
+            // the agent axis (the numpy API, ENV:487), else agent-major pairs [E][N][2]
+            if (act_f64 & 2) {
+                const size_t a0 = (size_t)e * n_a + i, a1 = a0 + (size_t)P.n_env * n_a;
+                if (act_f64 & 1) { ax = ((const double *)action)[a0]; ay = ((const double *)action)[a1]; }
+                else { ax = (double)((const float *)action)[a0]; ay = (double)((const float *)action)[a1]; }
+            }
+            else if (act_f64 & 1) { const size_t ab = ((size_t)e * n_a + i) * 2; ax = ((const double *)action)[ab]; ay = ((const double *)action)[ab + 1]; }
             else { const float2 af = reinterpret_cast<const float2 *>(action)[(size_t)e * n_a + i]; ax = (double)af.x; ay = (double)af.y; }
             // the prior policy of THIS step (CPP:1061-1196 via ENV:605-624) is a function of the pre-integration state and
             // of the neighbour list / nearest cell of the previous observation: the previous launch evaluated it at its end,
@@ -1635,13 +1646,15 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // that sits in LDS, and leaves it in HBM for the next launch; the other splits write its share of the head pairs.
     if (sx == SB && P.with_prior) {
         double qx = 0.0, qy = 0.0;
+        double lx = 0.0, ly = 0.0;                       // agent_strategy 'llm': the Python twin (ENV:892-940), other repulsion gain
         {
             const int ncf = sncf[at];
             // target: own position when in shape (CPP:889-897) => zero attraction; else the nearest cell
             double tx = px - px, ty = py - py;
             if (!(ncf >> 30)) { const double2 g = cell64(ncf & 0xFFFF); tx = g.x - px; ty = g.y - py; }
             const double dt_ = sqrt(tx * tx + ty * ty);
-            if (dt_ > 0) { qx += 2.0 * tx / dt_; qy += 2.0 * ty / dt_; }
+            if (dt_ > 0) { qx += P.pk_att * tx / dt_; qy += P.pk_att * ty / dt_; }
+            lx = qx; ly = qy;
             double avx = 0.0, avy = 0.0; int cnt = 0;
 #pragma unroll
             for (int k = 0; k < kTopoMax; ++k) {
@@ -1653,19 +1666,22 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 if (used && d2n > 0 && d2n < P.c_avoid) {            // 0 < d < r_avoid (CPP:1150-1160), d = sqrt(d2n): sqrt is monotonic
                     const double d = sqrt(d2n);
                     const double ux = x / d, uy = y / d;
-                    const double factor = 3.0 * (P.r_avoid / d - 1.0);
+                    const double factor = P.pk_rep * (P.r_avoid / d - 1.0);
                     qx += factor * ux; qy += factor * uy;
+                    if (P.llm) { const double fl = P.pk_llm * (P.r_avoid / d - 1.0); lx += fl * ux; ly += fl * uy; }
                 }
                 if (used) { avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt; }
             }
             if (cnt > 0) {
                 avx /= cnt; avy /= cnt;
-                qx += 2.0 * (avx - sp[2 * AG + at]); qy += 2.0 * (avy - sp[3 * AG + at]);
+                const double sxv = P.pk_ali * (avx - sp[2 * AG + at]), syv = P.pk_ali * (avy - sp[3 * AG + at]);
+                qx += sxv; qy += syv; lx += sxv; ly += syv;
             }
         }
         if (act) {
             OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
             reinterpret_cast<OT2 *>(P.prior_next)[(size_t)e * n_a + i] = o;
+            if (P.llm) { double2 u; u.x = clamp_ref(lx, -1.0, 1.0); u.y = clamp_ref(ly, -1.0, 1.0); P.act_next[(size_t)e * n_a + i] = u; }
         }
     }
 
@@ -2093,6 +2109,58 @@ k_interleave(const double *__restrict__ cells, double2 *__restrict__ out, int ng
 }
 
 // -------------------------------------------------------------------------------------------------
+// The reference-shaped host outputs ("a single host-side gather of obs / reward"): the step
+// leaves obs [E][N][D], reward [E][N], done [E][N], a_prior [E][N][2] on the device; the numpy API of
+// AssemblySwarmEnv.step returns obs (D, n_a) / reward (1, n_a) / a_prior (2, n_a) as float64 and done (1, n_a) as bool with
+// the environments side by side on the agent axis (assembly.py:487-666, 227-231, 353, 480-482).  k_export writes exactly
+// that block -- widened to double, transposed -- into ONE contiguous device buffer that a single hipMemcpyAsync moves
+// into pinned host memory: no per-step allocation, no host-side pass over the data.
+// Block layout (doubles): obs D*EN | a_prior 2*EN | reward EN | done EN bytes.
+// -------------------------------------------------------------------------------------------------
+template <typename OT> __device__ __forceinline__ double wide(OT v) { return (double)v; }
+template <> __device__ __forceinline__ double wide<__bf16>(__bf16 v) { return (double)(float)v; }
+
+template <typename OT>
+__global__ void __launch_bounds__(256)
+k_export(const OT *__restrict__ obs, const float *__restrict__ reward, const uint8_t *__restrict__ done,
+         const OT *__restrict__ prior, double *__restrict__ out, const int D, const long long EN, const int with_prior)
+{
+    // tile: 64 agent rows x 32 features through LDS: reads run along a row (features contiguous), writes along the agent axis
+    __shared__ double tile[32][65];
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * 64;
+    for (int f0 = 0; f0 < D; f0 += 32) {
+        const int fw = D - f0 < 32 ? D - f0 : 32;
+        {
+            const int f = tid & 31;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = (tid >> 5) + 8 * k;
+                if (f < fw && r0 + r < EN) tile[f][r] = wide<OT>(obs[(size_t)(r0 + r) * D + f0 + f]);
+            }
+        }
+        __syncthreads();
+        {
+            const int r = tid & 63;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = (tid >> 6) + 4 * k;
+                if (f < fw && r0 + r < EN) __builtin_nontemporal_store(tile[f][r], &out[(size_t)(f0 + f) * EN + r0 + r]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 64 && r0 + tid < EN) {
+        const long long a = r0 + tid;
+        double *pri = out + (size_t)D * EN, *rew = pri + 2 * EN;
+        uint8_t *dn = reinterpret_cast<uint8_t *>(rew + EN);
+        if (with_prior) { pri[a] = wide<OT>(prior[2 * a]); pri[EN + a] = wide<OT>(prior[2 * a + 1]); }
+        if (reward != nullptr) rew[a] = (double)reward[a];
+        if (done != nullptr) dn[a] = done[a];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 
@@ -2149,6 +2217,14 @@ struct swarm_env {
     int *d_nei, *d_near, *d_inflag, *d_ng, *d_exp_sensed, *d_exp_occ;
     unsigned long long *d_hit;
     void *d_prior;
+    double2 *d_act_next;           // [E][N] the 'llm' strategy's next action (cfg.llm_action)
+    // reference-shaped host I/O (swarm_step_host): library-owned step outputs on the device, the export block on the
+    // device, two pinned host copies of it (ping-pong: the previous step's arrays stay valid for one more step), a pinned
+    // staging buffer for the action
+    void *d_io_obs, *d_io_prior; float *d_io_rew; uint8_t *d_io_done;
+    double *d_io_block, *h_io_block[2];
+    void *h_io_action, *d_io_action;
+    size_t io_block_bytes;
 };
 
 namespace {
@@ -2419,6 +2495,8 @@ void swarm_default_config(swarm_config_t *c)
     c->d_sen = 0.4; c->r_avoid = 0.15; c->size_a = 0.035;
     c->k_ball = 30; c->k_wall = 100; c->c_wall = 5; c->vel_max = 0.8; c->dt = 0.1;
     c->boundary[0] = -2.4; c->boundary[1] = 2.4; c->boundary[2] = 2.4; c->boundary[3] = -2.4;
+    c->prior_gain[0] = 2.0; c->prior_gain[1] = 3.0; c->prior_gain[2] = 2.0;      // AssemblyEnv.cpp:1128-1132
+    c->llm_repulsion = 1.0; c->llm_action = 0;                                   // assembly.py:895
 }
 
 const char *swarm_last_error(const swarm_env_t *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -2458,6 +2536,9 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->lat_ncols.assign((size_t)cfg->n_env, 0);
     h->lattice_disabled = (cfg->debug_flags & 2) != 0;
     h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr; h->d_hit = nullptr; h->d_prior = nullptr;
+    h->d_act_next = nullptr;
+    h->d_io_obs = h->d_io_prior = nullptr; h->d_io_rew = nullptr; h->d_io_done = nullptr;
+    h->d_io_block = nullptr; h->h_io_block[0] = h->h_io_block[1] = nullptr; h->h_io_action = h->d_io_action = nullptr; h->io_block_bytes = 0;
     h->cells_set.assign((size_t)cfg->n_env, 0);
     h->npad = npad_for(cfg->n_agents);
 
@@ -2469,6 +2550,8 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     k.obs_dim = 2 * 2 * (k.topo + 1 + k.with_self) + 2 * k.g_max;               // ENV:801
     k.boundary = cfg->is_boundary ? 1 : 0; k.periodic = cfg->is_boundary ? 0 : 1;  // ENV:99-103
     k.with_prior = cfg->with_prior ? 1 : 0;
+    k.pk_att = cfg->prior_gain[0]; k.pk_rep = cfg->prior_gain[1]; k.pk_ali = cfg->prior_gain[2];
+    k.pk_llm = cfg->llm_repulsion; k.llm = cfg->llm_action ? 1 : 0;
     k.d_sen = cfg->d_sen; k.r_avoid = cfg->r_avoid; k.size_a = cfg->size_a;
     k.size2 = cfg->size_a + cfg->size_a;                                         // ENV:785-786
     k.k_ball = cfg->k_ball; k.k_wall = cfg->k_wall; k.c_wall = cfg->c_wall; k.vel_max = cfg->vel_max; k.dt = cfg->dt;
@@ -2538,11 +2621,13 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     alloc((void **)&h->d_cells_xy, E * (size_t)k.ng_max * 16);
     alloc((void **)&h->d_ng, E * 4); alloc((void **)&h->d_shape_idx, E * 4);
     alloc((void **)&h->d_prior, E * N * 16);
+    if (cfg->llm_action) alloc((void **)&h->d_act_next, E * N * 16);
     alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
     alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_hit, E * N * 8 * (size_t)std::max(1, h->npad / 64));
     if (a == hipSuccess) a = hipMemset(h->d_ng, 0, E * 4);
     if (a == hipSuccess) a = hipMemset(h->d_prior, 0, E * N * 16);
+    if (a == hipSuccess && h->d_act_next) a = hipMemset(h->d_act_next, 0, E * N * 16);
     if (a == hipSuccess) a = hipMemset(h->d_shape_idx, 0xFF, E * 4);
     if (a == hipSuccess) a = hipMemset(h->d_nei, 0xFF, E * N * (size_t)k.topo * 4);
     if (a == hipSuccess) a = hipMemset(h->d_near, 0, E * N * 4);
@@ -2558,7 +2643,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
         return fail(nullptr, SWARM_ERR_HIP, m);
     }
     k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag; k.hit = h->d_hit;
-    k.prior_next = h->d_prior;
+    k.prior_next = h->d_prior; k.act_next = h->d_act_next;
     k.cells = h->d_cells; k.cells_xy = h->d_cells_xy; k.n_g = h->d_ng; k.c_in = h->d_cin;
     k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_nrs = k.lat_nrc = 0; k.lat_n32 = 0;
     k.c_near_hi = k.c_near * (1.0 + 1e-9);
@@ -2576,6 +2661,11 @@ int swarm_destroy(swarm_env_t *h)
         (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag); (void)hipFree(h->d_hit);
         (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat); (void)hipFree(h->d_shape_idx); (void)hipFree(h->d_prior);
         (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
+        (void)hipFree(h->d_act_next); (void)hipFree(h->d_io_obs); (void)hipFree(h->d_io_prior); (void)hipFree(h->d_io_rew); (void)hipFree(h->d_io_done);
+        (void)hipFree(h->d_io_block); (void)hipFree(h->d_io_action);
+        if (h->h_io_block[0]) (void)hipHostFree(h->h_io_block[0]);
+        if (h->h_io_block[1]) (void)hipHostFree(h->h_io_block[1]);
+        if (h->h_io_action) (void)hipHostFree(h->h_io_action);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
     }
@@ -2792,11 +2882,121 @@ int swarm_observe(swarm_env_t *h, void *obs)
 int swarm_step(swarm_env_t *h, const void *action, int action_dtype, void *obs, float *reward, uint8_t *done, void *a_prior)
 {
     if (!h) return SWARM_ERR_INVALID;
-    if (!action) return fail(h, SWARM_ERR_INVALID, "swarm_step: null action");
+    if (!action) {
+        // agent_strategy == 'llm' (assembly.py:525-529): the action is the Python twin of the prior policy, which the
+        // previous pass evaluated on this very state
+        if (!h->cfg.llm_action) return fail(h, SWARM_ERR_INVALID, "swarm_step: null action (only a handle created with llm_action may pass NULL)");
+        action = h->d_act_next; action_dtype = SWARM_F64;
+    }
     if (action_dtype != SWARM_F32 && action_dtype != SWARM_F64) return fail(h, SWARM_ERR_INVALID, "swarm_step: bad action_dtype");
     if (!h->observed) return fail(h, SWARM_ERR_STATE, "swarm_step: call swarm_observe after setting cells/state (the reference's reset() ends with _get_obs())");
     DeviceGuard g(h->device);
     return launch(h, true, action, action_dtype == SWARM_F64, obs, reward, done, a_prior);
+}
+
+namespace {
+int io_alloc(swarm_env *h)
+{
+    if (h->d_io_block) return SWARM_OK;
+    const size_t EN = (size_t)h->cfg.n_env * h->cfg.n_agents, D = (size_t)h->kp.obs_dim;
+    const size_t so = h->cfg.obs_dtype == SWARM_F64 ? 8 : h->cfg.obs_dtype == SWARM_BF16 ? 2 : 4;
+    h->io_block_bytes = (D * EN + 2 * EN + EN) * 8 + ((EN + 15) & ~size_t(15));
+    HIP_TRY(h, hipMalloc(&h->d_io_obs, EN * D * so));
+    HIP_TRY(h, hipMalloc(&h->d_io_prior, EN * 2 * so));
+    HIP_TRY(h, hipMalloc((void **)&h->d_io_rew, EN * 4));
+    HIP_TRY(h, hipMalloc((void **)&h->d_io_done, EN));
+    HIP_TRY(h, hipMalloc((void **)&h->d_io_block, h->io_block_bytes));
+    HIP_TRY(h, hipMalloc(&h->d_io_action, EN * 16));
+    HIP_TRY(h, hipHostMalloc((void **)&h->h_io_block[0], h->io_block_bytes, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc((void **)&h->h_io_block[1], h->io_block_bytes, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&h->h_io_action, EN * 16, hipHostMallocDefault));
+    HIP_TRY(h, hipMemset(h->d_io_block, 0, h->io_block_bytes));
+    std::memset(h->h_io_block[0], 0, h->io_block_bytes); std::memset(h->h_io_block[1], 0, h->io_block_bytes);
+    return SWARM_OK;
+}
+
+int io_export(swarm_env *h, int slot, bool stepped)
+{
+    const long long EN = (long long)h->cfg.n_env * h->cfg.n_agents;
+    const int D = h->kp.obs_dim, wp = (stepped && h->kp.with_prior) ? 1 : 0;
+    const unsigned grid = (unsigned)((EN + 63) / 64);
+    const float *rew = stepped ? h->d_io_rew : nullptr;
+    const uint8_t *dn = stepped ? h->d_io_done : nullptr;
+    if (h->cfg.obs_dtype == SWARM_F64)
+        hipLaunchKernelGGL(k_export<double>, dim3(grid), dim3(256), 0, h->stream, (const double *)h->d_io_obs, rew, dn, (const double *)h->d_io_prior, h->d_io_block, D, EN, wp);
+    else if (h->cfg.obs_dtype == SWARM_BF16)
+        hipLaunchKernelGGL(k_export<__bf16>, dim3(grid), dim3(256), 0, h->stream, (const __bf16 *)h->d_io_obs, rew, dn, (const __bf16 *)h->d_io_prior, h->d_io_block, D, EN, wp);
+    else
+        hipLaunchKernelGGL(k_export<float>, dim3(grid), dim3(256), 0, h->stream, (const float *)h->d_io_obs, rew, dn, (const float *)h->d_io_prior, h->d_io_block, D, EN, wp);
+    HIP_TRY(h, hipGetLastError());
+    // obs only (reset / observe) moves the obs part; a step moves the whole block
+    const size_t bytes = stepped ? h->io_block_bytes : (size_t)D * EN * 8;
+    HIP_TRY(h, hipMemcpyAsync(h->h_io_block[slot], h->d_io_block, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWARM_OK;
+}
+}  // namespace
+
+int swarm_get_llm_action(swarm_env_t *h, double *action)
+{
+    if (!h || !action) return SWARM_ERR_INVALID;
+    if (!h->d_act_next) return fail(h, SWARM_ERR_STATE, "swarm_get_llm_action: handle was not created with llm_action");
+    if (!h->observed) return fail(h, SWARM_ERR_STATE, "swarm_get_llm_action: nothing observed yet");
+    DeviceGuard g(h->device);
+    HIP_TRY(h, hipMemcpyAsync(action, h->d_act_next, (size_t)h->cfg.n_env * h->cfg.n_agents * 16, hipMemcpyDefault, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SWARM_OK;
+}
+
+int swarm_host_outputs(swarm_env_t *h, int slot, swarm_host_out_t *out)
+{
+    if (!h || !out || slot < 0 || slot > 1) return SWARM_ERR_INVALID;
+    DeviceGuard g(h->device);
+    int rc = io_alloc(h);
+    if (rc != SWARM_OK) return rc;
+    const size_t EN = (size_t)h->cfg.n_env * h->cfg.n_agents, D = (size_t)h->kp.obs_dim;
+    double *b = h->h_io_block[slot];
+    out->obs = b; out->a_prior = b + D * EN; out->reward = b + D * EN + 2 * EN;
+    out->done = reinterpret_cast<uint8_t *>(b + D * EN + 3 * EN);
+    return SWARM_OK;
+}
+
+int swarm_observe_host(swarm_env_t *h, int slot)
+{
+    if (!h || slot < 0 || slot > 1) return SWARM_ERR_INVALID;
+    DeviceGuard g(h->device);
+    int rc = io_alloc(h);
+    if (rc != SWARM_OK) return rc;
+    rc = swarm_observe(h, h->d_io_obs);
+    if (rc != SWARM_OK) return rc;
+    return io_export(h, slot, false);
+}
+
+int swarm_step_host(swarm_env_t *h, const void *action, int action_dtype, int action_on_device, int slot)
+{
+    if (!h || slot < 0 || slot > 1) return SWARM_ERR_INVALID;
+    if (action && action_dtype != SWARM_F32 && action_dtype != SWARM_F64) return fail(h, SWARM_ERR_INVALID, "swarm_step_host: bad action_dtype");
+    if (!h->observed) return fail(h, SWARM_ERR_STATE, "swarm_step_host: call swarm_observe(_host) after setting cells/state");
+    DeviceGuard g(h->device);
+    int rc = io_alloc(h);
+    if (rc != SWARM_OK) return rc;
+    const size_t EN = (size_t)h->cfg.n_env * h->cfg.n_agents;
+    const void *act = action; int mode = 0;
+    if (!action) {
+        if (!h->cfg.llm_action) return fail(h, SWARM_ERR_INVALID, "swarm_step_host: null action");
+        act = h->d_act_next; mode = 1;                                   // agent-major doubles
+    } else if (action_on_device) {
+        mode = action_dtype == SWARM_F64 ? 1 : 0;                        // [E][N][2] device tensor, as swarm_step
+    } else {
+        // the reference's (2, n_a) host array: through the pinned staging buffer, read component-major by the kernel
+        const size_t bytes = EN * 2 * (action_dtype == SWARM_F64 ? 8 : 4);
+        std::memcpy(h->h_io_action, action, bytes);
+        HIP_TRY(h, hipMemcpyAsync(h->d_io_action, h->h_io_action, bytes, hipMemcpyHostToDevice, h->stream));
+        act = h->d_io_action; mode = 2 | (action_dtype == SWARM_F64 ? 1 : 0);
+    }
+    rc = launch(h, true, act, mode, h->d_io_obs, h->d_io_rew, h->d_io_done, h->kp.with_prior ? h->d_io_prior : nullptr);
+    if (rc != SWARM_OK) return rc;
+    return io_export(h, slot, true);
 }
 
 int swarm_get_indices(swarm_env_t *h, int32_t *neighbor_index, int32_t *in_flags, int32_t *sensed_index, int32_t *occupied_index)

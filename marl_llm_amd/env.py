@@ -55,7 +55,7 @@ class Agent:                                    # assembly_wrapper.py:5-16
 class AssemblySwarmEnv(_EnvBase):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 45}
 
-    def __init__(self, n_envs=1, device="cuda:0", obs_dtype="float64", rng="global", seed=226):
+    def __init__(self, n_envs=1, device="cuda:0", obs_dtype="float64", rng="global", seed=226, host_copy="auto"):
         # constants of assembly.py:18-81
         self.reward_sharing_mode = "individual"
         self.penalize_entering = self.penalize_interaction = self.penalize_exploration = True
@@ -81,6 +81,12 @@ class AssemblySwarmEnv(_EnvBase):
         self._seed = seed
         self._batch = None
         self._cells_dirty = False
+        # numpy API: the library hands out views of two pinned host slots that it rewrites every second call.  The
+        # reference returns fresh arrays; host_copy=True copies them (always safe), False returns the views (valid until the
+        # call after the next -- what the reference's trainer needs, train_assembly.py:97-111), "auto" copies below 4 MB.
+        self._host_copy = host_copy
+        self._state_version = 0
+        self._metrics_cache = (None, None)
 
     # ------------------------------------------------------------------ configuration (assembly.py:92-154)
     def __reinit__(self, args):
@@ -100,10 +106,8 @@ class AssemblySwarmEnv(_EnvBase):
         self.alpha = 1
         if self.dynamics_mode != "Cartesian":
             raise ValueError("only dynamics_mode='Cartesian' exists in the reference (assembly.py:141-146)")
-        if self.agent_strategy not in ("input", "random", "rule"):
-            # 'llm' drives the agents with the Python twin of the prior (assembly.py:892-940, other constants than the
-            # deployed C++ prior); nothing in marl_llm/ selects it
-            raise NotImplementedError("agent_strategy %r: 'input', 'random' and 'rule' are on the GPU path" % (self.agent_strategy,))
+        if self.agent_strategy not in ("input", "random", "rule", "llm"):
+            raise ValueError("agent_strategy %r: the reference knows 'input', 'random', 'rule' and 'llm' (assembly.py:521-603)" % (self.agent_strategy,))
 
         results = args.results_file if isinstance(args.results_file, dict) else load_results(args.results_file)
         self.l_cells = list(results["l_cell"])
@@ -133,7 +137,11 @@ class AssemblySwarmEnv(_EnvBase):
             dt = torch.float64 if self._obs_dtype in ("float64", "f64") else torch.float32
             self._batch = SwarmBatch(n_env=self.n_envs, n_agents=self.n_agents_per_env, n_cells_max=self.n_cells_max,
                                      r_avoid=self.r_avoid, is_boundary=self.is_boundary,
-                                     with_self=self.is_con_self_state, with_prior=(self.training_method == "llm_rl"),
+                                     with_self=self.is_con_self_state,
+                                     # 'llm': the agents are driven by the Python twin of the prior (assembly.py:525-529,892-940),
+                                     # evaluated on the device next to the prior itself
+                                     with_prior=(self.training_method == "llm_rl" or self.agent_strategy == "llm"),
+                                     llm_action=(self.agent_strategy == "llm"),
                                      obs_dtype=dt, device=self._device, d_sen=0.4,
                                      topo=self.topo_nei_max, g_max=self.num_obs_grid_max,
                                      occ_max=self.num_occupied_grid_max,
@@ -172,7 +180,7 @@ class AssemblySwarmEnv(_EnvBase):
             p[e] = pe; dp[e] = dpe; shape_idx[e] = s
         return dict(cells=cells, n_g=n_g, l_cell=l_cell, p=p, dp=dp, shape_index=shape_idx)
 
-    def reset_tensor(self):
+    def reset_tensor(self, _observe=True):
         """reset() returning the device observation tensor [E, N, D].
 
         rng="global" (default): the reference's draw order from numpy's global RNG on the host (seed-for-seed parity,
@@ -205,10 +213,22 @@ class AssemblySwarmEnv(_EnvBase):
         b.set_cells(self._cells, self._n_g, self._l_cell)
         b.set_state(s["p"], s["dp"])
         self._cells_dirty = False
-        return b.observe()
+        return b.observe() if _observe else None
 
     def reset(self):
-        return self._obs_to_numpy(self.reset_tensor())
+        self.reset_tensor(_observe=False)         # draws + uploads; the observation pass runs once, in observe_host
+        return self._host_obs(self._backend().observe_host())
+
+    def _own(self, a):
+        """A host-slot view as the caller gets it: a copy unless host_copy says views are fine."""
+        c = self._host_copy
+        if c is True or (c == "auto" and a.nbytes <= (4 << 20)):
+            return a.copy()
+        return a
+
+    def _host_obs(self, obs):
+        self._state_version += 1
+        return self._own(obs)
 
     def _flush_cells(self):
         """Upload target cells that were assigned through the attribute setters and refresh the obs-derived caches.
@@ -222,41 +242,66 @@ class AssemblySwarmEnv(_EnvBase):
             b.set_cells(self._cells, self._n_g, self._l_cell)
             b.observe()
             self._cells_dirty = False
+            self._state_version += 1
         return b
 
     # ------------------------------------------------------------------ step (assembly.py:487-666)
+    def _strategy_action(self, b, action):
+        """The action the reference's step applies (assembly.py:521-603): the passed one ('input'), a uniform draw from
+        numpy's global stream ('random'), the rule-based expert ('rule', device) or the prior's Python twin ('llm': None =
+        the library's own device-side action)."""
+        if self.agent_strategy == "rule":
+            return b.rule_action()
+        if self.agent_strategy == "random":
+            return np.random.uniform(-1, 1, (self.act_dim_agent, self.n_a))           # assembly.py:523-524
+        if self.agent_strategy == "llm":
+            return None
+        return action
+
     def step_tensor(self, action):
         """action [E, N, 2] device tensor -> (obs [E,N,D], reward [E,N], done [E,N] uint8, a_prior [E,N,2] | None)."""
+        import torch
         b = self._flush_cells()
         self.simulation_time += self.dt
-        if self.agent_strategy == "rule":          # assembly.py:530-601: the expert controller replaces the passed action
-            action = b.rule_action()
-        elif self.agent_strategy == "random":      # assembly.py:523-524 (numpy's global stream, one draw per step)
-            import torch
+        self._state_version += 1
+        action = self._strategy_action(b, action)
+        if isinstance(action, np.ndarray):
             E, N = self.n_envs, self.n_agents_per_env
-            u = np.random.uniform(-1, 1, (self.act_dim_agent, self.n_a))
-            action = torch.as_tensor(np.ascontiguousarray(u.T.reshape(E, N, 2)), device=b.device)
+            action = torch.as_tensor(np.ascontiguousarray(action.T.reshape(E, N, 2)), device=b.device)
+        applied = b.llm_action() if (action is None and self.is_collected) else action
         obs, rew, done, pri = b.step(action)
+        if self.training_method != "llm_rl":
+            pri = None
         if self.is_collected:                      # assembly.py:663-664: the applied action is returned instead of the prior
-            pri = action
+            pri = applied
         return obs, rew, done, pri
 
     def step(self, a):
-        import torch
+        """The reference's numpy API (assembly.py:487-666): a (2, n_a) -> (obs (D, n_a) f64, rew (1, n_a) f64, done (1, n_a)
+        bool, info, a_prior (2, n_a) f64 | None | u).  One library call: the action goes up through a pinned staging buffer,
+        the outputs come back widened / transposed on the device in one copy into pinned memory (swarm_step_host)."""
         E, N = self.n_envs, self.n_agents_per_env
         a = np.asarray(a)
         if a.shape != (self.act_dim_agent, self.n_a):
             raise ValueError("action must have shape %r" % ((self.act_dim_agent, self.n_a),))
-        dt = torch.float64 if a.dtype == np.float64 else torch.float32
-        act = torch.as_tensor(np.ascontiguousarray(a.T.reshape(E, N, 2)), dtype=dt, device=self._backend().device)
-        obs, rew, done, pri = self.step_tensor(act)
-        obs_np = self._obs_to_numpy(obs)
-        rew_np = rew.reshape(1, E * N).to(torch.float64).cpu().numpy()                # (1, n_a), assembly.py:353
-        done_np = done.reshape(1, E * N).cpu().numpy().astype(bool)                   # (1, n_a) bool, :480-482
+        b = self._flush_cells()
+        self.simulation_time += self.dt
+        act = self._strategy_action(b, a)
+        applied = None
+        if self.is_collected:                      # assembly.py:663-664: u, the applied action, is the fifth element
+            if act is None:
+                applied = np.ascontiguousarray(b.llm_action().reshape(E * N, 2).cpu().numpy().T)
+            elif isinstance(act, np.ndarray):
+                applied = np.array(act, dtype=np.float64)
+            else:
+                applied = np.ascontiguousarray(act.reshape(E * N, 2).to("cpu").numpy().astype(np.float64).T)
+        out = b.step_host(act)
+        obs_np = self._host_obs(out["obs"])
+        rew_np, done_np = self._own(out["reward"]), self._own(out["done"])
         info = np.array([None, None, None]).reshape(3, 1)                             # :484-485
-        pri_np = None
-        if pri is not None:
-            pri_np = np.ascontiguousarray(pri.reshape(E * N, 2).to(torch.float64).cpu().numpy().T)   # (2, n_a)
+        pri_np = self._own(out["a_prior"]) if self.training_method == "llm_rl" else None
+        if self.is_collected:
+            pri_np = applied
         return obs_np, rew_np, done_np, info, pri_np
 
     def _obs_to_numpy(self, obs):
@@ -283,7 +328,7 @@ class AssemblySwarmEnv(_EnvBase):
             p = p.reshape(2, E, N).transpose(1, 0, 2); dp = dp.reshape(2, E, N).transpose(1, 0, 2)
         b = self._flush_cells() if getattr(self, "_cells", None) is not None else self._backend()
         b.set_state(np.ascontiguousarray(p), np.ascontiguousarray(dp))
-        return self._obs_to_numpy(b.observe())
+        return self._host_obs(b.observe_host())
 
     def indices(self):
         """neighbor_index / in_flags / sensed_index / occupied_index of the current state (numpy)."""
@@ -292,7 +337,12 @@ class AssemblySwarmEnv(_EnvBase):
     def metrics_tensor(self):
         """[E, 3] float64 device tensor: coverage_rate, distribution_uniformity, voronoi_based_uniformity per env
         (assembly_wrapper.py:48-128) of the current state and the CURRENT target cells."""
-        return self._flush_cells().metrics()
+        b = self._flush_cells()
+        ver, val = self._metrics_cache
+        if ver != self._state_version:             # the three wrapper metrics of one state share one launch + one read-back
+            val = b.metrics()
+            self._metrics_cache = (self._state_version, val)
+        return val
 
     # grid_center / n_g / l_cell: readable and writable like the reference's attributes (env 0 when E > 1)
     @property
@@ -362,14 +412,20 @@ class AssemblySwarmWrapper(_WrapperBase):
         return getattr(self.env, name)
 
     # evaluation metrics (assembly_wrapper.py:48-128), computed on the device; env 0 when several envs are batched
+    def _metrics_host(self):
+        t = self.env.metrics_tensor()
+        if getattr(self, "_mh", (None, None))[0] is not t:
+            self._mh = (t, t[0].cpu().numpy())
+        return self._mh[1]
+
     def coverage_rate(self):
-        return float(self.env.metrics_tensor()[0, 0].item())
+        return float(self._metrics_host()[0])
 
     def distribution_uniformity(self):
-        return float(self.env.metrics_tensor()[0, 1].item())
+        return float(self._metrics_host()[1])
 
     def voronoi_based_uniformity(self):
-        return float(self.env.metrics_tensor()[0, 2].item())
+        return float(self._metrics_host()[2])
 
     def render(self, mode="human", **kw):
         return self.env.render(mode=mode, **kw)

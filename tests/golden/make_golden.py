@@ -14,6 +14,7 @@ shape set of marl_llm_amd/shapes.py written in the reference's pickle layout to 
 Usage:  MPLBACKEND=Agg python tests/golden/make_golden.py        (round-1 fixtures g1..g5)
         MPLBACKEND=Agg python tests/golden/make_golden.py r2     (round-2 fixtures: real shapes, thicker g2, reset
                                                                   statistics, learner-side modules)
+        MPLBACKEND=Agg python tests/golden/make_golden.py r3     (round-3 fixtures: agent_strategy == 'llm')
 """
 import ctypes
 import os
@@ -283,8 +284,37 @@ def main_r2():
     print("done ->", HERE)
 
 
+def main_r3():
+    """Round-3 fixtures: agent_strategy == 'llm' (assembly.py:525-529: the agents are driven by robot_prior_policy, the
+    Python twin of the prior with repulsion gain 1.0, assembly.py:892-940).  is_collected makes step() return the applied
+    action u (assembly.py:663-664)."""
+    gym, Wrapper = import_reference_env()
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    pkl = os.path.join(tmp, "results.pkl")
+    save_results(pkl, synthetic_shape_set())
+    for n_a, keep_from, steps in ((8, 50, 56), (32, 70, 76)):
+        np.random.seed(700 + n_a)
+        env = make_env(gym, Wrapper, n_a, pkl, strategy="llm", collected=True)
+        env.reset()
+        b = env.env
+        rec = {k: [] for k in ("p", "dp", "nei_prev", "u", "p_next", "dp_next", "rew", "obs")}
+        for t in range(steps):
+            pre_p, pre_dp, pre_nei = b.p.copy(), b.dp.copy(), b.neighbor_index.copy()
+            o, r, d, _, u = env.step(np.zeros((2, n_a), np.float32))          # the passed action is ignored in llm mode
+            if t >= keep_from:
+                rec["p"].append(pre_p); rec["dp"].append(pre_dp); rec["nei_prev"].append(pre_nei); rec["u"].append(u.copy())
+                rec["p_next"].append(b.p.copy()); rec["dp_next"].append(b.dp.copy()); rec["rew"].append(r.copy())
+                rec["obs"].append(o.copy())
+        out = {k: np.stack(v) for k, v in rec.items()}
+        out.update(grid=b.grid_center.copy(), l_cell=np.float64(b.l_cell), r_avoid=np.float64(b.r_avoid), d_sen=np.float64(b.d_sen))
+        np.savez_compressed(os.path.join(HERE, f"g10_llm_n{n_a}.npz"), **out)
+        print("g10_llm", n_a, "|u| max", np.abs(out["u"]).max(), "reward", out["rew"].sum((1, 2)))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "r2":
         main_r2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "r3":
+        main_r3()
     else:
         main()

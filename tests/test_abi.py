@@ -59,10 +59,11 @@ def test_config_struct_matches_header(lib):
     from marl_llm_amd._lib import SwarmConfig
     cfg = SwarmConfig()
     lib.swarm_default_config(ctypes.byref(cfg))
-    assert ctypes.sizeof(SwarmConfig) == 12 * 4 + 12 * 8
+    assert ctypes.sizeof(SwarmConfig) == 12 * 4 + 12 * 8 + 4 * 8 + 2 * 4      # + prior_gain[3], llm_repulsion, llm_action, pad
     assert (cfg.topo_nei_max, cfg.num_obs_grid_max, cfg.num_occupied_grid_max) == (6, 80, 200)
     assert (cfg.d_sen, cfg.size_a, cfg.k_ball, cfg.k_wall, cfg.c_wall, cfg.vel_max, cfg.dt) == (0.4, 0.035, 30, 100, 5, 0.8, 0.1)
     assert list(cfg.boundary) == [-2.4, 2.4, 2.4, -2.4]
+    assert list(cfg.prior_gain) == [2.0, 3.0, 2.0] and cfg.llm_repulsion == 1.0 and cfg.llm_action == 0
 
 
 def test_invalid_configs_rejected_with_message(lib):

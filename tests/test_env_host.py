@@ -45,5 +45,6 @@ def test_surface_and_spaces(shapes):
 def test_unsupported_modes_fail_loudly(shapes):
     with pytest.raises(ValueError):
         _env(shapes, dynamics_mode="Polar")
-    with pytest.raises(NotImplementedError):
-        _env(shapes, agent_strategy="llm")
+    with pytest.raises(ValueError):
+        _env(shapes, agent_strategy="greedy")      # the reference's step prints 'Wrong in Step function' (assembly.py:602-603)
+    assert _env(shapes, agent_strategy="llm").agent_strategy == "llm"      # all four of the reference's strategies configure
