@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed steps of the same loop issued right before --warmup until this much GPU time has passed")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--latency-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -314,9 +315,136 @@ def measure(torch, n_a, E, state, steps, warmup, assemble_steps, seed, env_offse
     return sb, sy, r_avoid, timed, prewarm
 
 
+def latency_worker_main():
+    """Child process (part of the CPU-baseline leg: it loads oracle/): per-step latency of the REFERENCE at its own
+    scale -- one env, its numpy glue (restated: oracle_py.ref_step) around the five native calls -- with the calls going
+    (a) to the reference's own libAssemblyEnv.so (oracle/_ref) and (b) to this library's legacy symbols, the same
+    signatures served by HIP kernels (BASELINE config 0: '8 agents x 1 env, plumbing').  Prints one JSON line."""
+    from oracle.oracle_py import Oracle, RefLib, ref_step
+    from marl_llm_amd import _lib
+    from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
+    from marl_llm_amd.synth import synthetic_batch
+    shapes = synthetic_shape_set()
+    out = {}
+    ours = RefLib.__new__(RefLib)
+    ours.lib = _lib.load()
+    have_ref = RefLib.available()
+    ref = RefLib() if have_ref else None
+    orc = Oracle()
+    for n_a in (8, 30):
+        ra = r_avoid_for(n_a, shapes)
+        sy = synthetic_batch(1, n_a, shapes, seed=226, assembled_fraction=0.6)
+        g = np.ascontiguousarray(sy["cells"][0][:, : sy["n_g"][0]])
+        l_cell = float(sy["l_cell"][0])
+        nei0 = orc.get_observation(sy["p"][0], sy["dp"][0], g, l_cell, ra)["neighbor_index"]
+        for name, lib in (("reference_cpu", ref), ("legacy_shim_gpu", ours)):
+            if lib is None:
+                continue
+            p, dp, nei, a = sy["p"][0].copy(), sy["dp"][0].copy(), nei0.copy(), np.zeros((2, n_a))
+            for k in range(230):
+                if k == 30:
+                    t0 = time.perf_counter()
+                s_ = ref_step(lib, p, dp, a, g, nei, l_cell, ra)
+                p, dp, nei = s_["p"], s_["dp"], s_["neighbor_index"]
+                a = s_["a_prior"].astype(np.float32).astype(np.float64)
+            out[f"{name}_n{n_a}_ms_per_step"] = (time.perf_counter() - t0) / 200 * 1e3
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def extra_configs(torch, args, device):
-    """other_configs beyond the kernel shapes: the numpy drop-in API, the legacy shim, the device rollout (filled in below)."""
-    return []
+    """other_configs beyond the kernel shapes: the numpy drop-in API (the path the unchanged trainer drives,
+    train_assembly.py:97-111) at the reference's default scale and at the headline batch, the legacy shim, the device
+    rollout."""
+    from marl_llm_amd.env import AssemblySwarmEnv, make_args
+    from marl_llm_amd.shapes import synthetic_shape_set
+    res = []
+    shapes = synthetic_shape_set()
+    # (1) reference-scale latency of the reference itself and of the legacy shim (child process: it may load oracle/)
+    lat = {}
+    try:
+        o = subprocess.run([sys.executable, os.path.abspath(__file__), "--latency-worker"], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        lat = json.loads(o.stdout.strip().splitlines()[-1])
+    except Exception as ex:                                            # reported, never fatal for the bench line
+        lat = {"error": repr(ex)[:200]}
+    # (2) numpy API, 1 env x 30 agents (assembly_cfg.py:153 default): obs / reward / prior come back as the reference's
+    #     float64 host arrays every step
+    for n_envs, n_a, steps in ((1, 30, 300), (4096, 64, 12)):
+        env = AssemblySwarmEnv(n_envs=n_envs, device=device, obs_dtype="float64", rng="counter", seed=args.seed, host_copy=False)
+        env.__reinit__(make_args(n_a=n_a, results_file=shapes))
+        env.reset()
+        a = np.zeros((2, n_envs * n_a), np.float32)
+        for _ in range(5 if n_envs > 1 else 50):                       # assemble a little, warm up
+            a = env.step(a)[4].astype(np.float32)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a = env.step(a)[4].astype(np.float32)                      # the trainer's loop shape: host action from host outputs
+        total_ms = (time.perf_counter() - t0) / steps * 1e3
+        b = env._backend()
+        act = torch.zeros((n_envs, n_a, 2), device=b.device)
+        b.timer_start()
+        for _ in range(steps):
+            b.step(act)
+        dev_ms = b.timer_stop() / steps
+        rec = {"workload": f"numpy drop-in API (AssemblySwarmEnv.step), {n_a} agents x {n_envs} env(s), float64 host arrays in the reference's layouts",
+               "ms_per_step": total_ms, "agent_steps_per_s": n_envs * n_a / (total_ms * 1e-3),
+               "device_step_kernel_ms": dev_ms,
+               "host_boundary_ms": total_ms - dev_ms,
+               "what": "one C call per step: pinned action staging -> H2D -> k_env (f64 rows) -> k_export (widen + transpose on the "
+                       "device) -> ONE D2H into a pinned slot -> sync; host_boundary_ms = everything but the step kernel "
+                       "(incl. the caller's astype of the next action)"}
+        if n_envs == 1:
+            rec["reference_cpu_ms_per_step"] = lat.get("reference_cpu_n30_ms_per_step")
+        else:
+            blk = b.obs_dim * n_envs * n_a * 8 + 3 * n_envs * n_a * 8 + n_envs * n_a
+            rec["host_block_bytes"] = blk
+            rec["d2h_GBps_if_all_boundary_time_were_the_copy"] = blk / ((total_ms - dev_ms) * 1e-3) / 1e9
+        res.append(rec)
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+    # (3) BASELINE config 0: the reference's own step (numpy glue + five native calls) at N = 8, native calls served by the
+    #     reference's library on one host core vs by this library's legacy symbols (synchronous H2D / kernel / D2H per call)
+    res.append({"workload": "assembly env, 8 agents x 1 env through the reference's five extern-C symbols (BASELINE config 0)",
+                "what": "ms per reference-style step (numpy glue + 5 native calls): reference libAssemblyEnv.so on one core vs "
+                        "this library's legacy symbols (GPU-backed; plumbing, not a fast path)", **lat})
+    # (4) device-resident rollout step (SURVEY 8f rank 1): env + fused policy (+ exploration noise) + replay push
+    try:
+        res.append(rollout_numbers(torch, args, device))
+    except Exception as ex:
+        res.append({"workload": "device rollout", "error": repr(ex)[:300]})
+    return res
+
+
+def rollout_numbers(torch, args, device):
+    from marl_llm_amd.batched import SwarmBatch
+    from marl_llm_amd.rollout import ChainedReplay, FusedPolicy, PolicyMLP, rollout
+    from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
+    shapes = synthetic_shape_set()
+    n_a, E, steps = 64, 4096, 100
+    ng_max = max(np.asarray(g).shape[0] for g in shapes["grid_coords"])
+    out = {"workload": "device-resident rollout step, 64 agents x 4096 envs: fused bf16 MFMA actor + exploration noise + env step "
+                       "(+ ChainedReplay push)", "what": "ms per rollout step, everything on the device (marl_llm_amd/rollout.py)"}
+    for tag, odt in (("f32_rows", torch.float32), ("bf16_rows", torch.bfloat16)):
+        sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=ng_max, r_avoid=r_avoid_for(n_a, shapes), obs_dtype=odt, device=device)
+        sb.set_shapes(shapes)
+        obs = sb.reset(seed=args.seed)
+        pol = FusedPolicy(PolicyMLP(obs_dim=sb.obs_dim).to(sb.device), device=sb.device)
+        rep = ChainedReplay(8, E * n_a, sb.obs_dim, 2, sb.device, obs_dtype=odt)
+        state = {"obs": obs}
+
+        def run(k, replay):
+            state["obs"], _ = rollout(sb, pol, k, state["obs"], replay=replay, noise_scale=0.1)
+
+        for replay, key in ((None, "env_policy_noise_ms"), (rep, "env_policy_noise_replay_ms")):
+            run(60, replay); torch.cuda.synchronize()
+            t0 = time.perf_counter(); run(steps, replay); torch.cuda.synchronize()
+            out[f"{tag}_{key}"] = (time.perf_counter() - t0) / steps * 1e3
+        sb.close()
+        del sb, pol, rep
+        torch.cuda.empty_cache()
+    return out
 
 
 def claim_stdout():
@@ -367,6 +495,8 @@ def main():
     args = parse()
     if args.cpu_worker:
         sys.exit(cpu_worker_main())
+    if args.latency_worker:
+        sys.exit(latency_worker_main())
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr); sys.exit(2)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
