@@ -37,6 +37,13 @@ int  swarm_policy_forward(swarm_policy_t *p, const float *obs, int64_t rows, flo
  * swarm_policy_forward on the same values held in float32. */
 int  swarm_policy_forward_bf16(swarm_policy_t *p, const void *obs_bf16, int64_t rows, float *act, void *stream);
 
+/* The rollout's exploring actor in one launch (agents.py:82-96, continuous branch): act = clamp(actor(obs) + noise_scale *
+ * N(0, 1), -1, 1).  The normals come from a counter-based generator keyed by (seed, step, row, component) -- any row range
+ * reproducible on any rank, nothing to store -- evaluated in the kernel's epilogue; noise_scale <= 0: plain forward.
+ * `act` may point anywhere on the device (e.g. straight into a replay-buffer slot).  obs_is_bf16 as the two calls above. */
+int  swarm_policy_forward_explore(swarm_policy_t *p, const void *obs, int obs_is_bf16, int64_t rows, float *act,
+                                  float noise_scale, uint64_t seed, uint64_t step, void *stream);
+
 const char *swarm_policy_last_error(void);
 
 #ifdef __cplusplus

@@ -38,7 +38,8 @@ BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", 
                    "swarm_get_state", "swarm_observe", "swarm_step", "swarm_get_indices",
                    "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_get_shape_index", "swarm_metrics", "swarm_rule_action",
                    "swarm_host_outputs", "swarm_observe_host", "swarm_step_host", "swarm_get_llm_action")
-POLICY_SYMBOLS = ("swarm_policy_create", "swarm_policy_destroy", "swarm_policy_forward", "swarm_policy_forward_bf16", "swarm_policy_last_error")   # include/swarm_policy.h
+POLICY_SYMBOLS = ("swarm_policy_create", "swarm_policy_destroy", "swarm_policy_forward", "swarm_policy_forward_bf16",
+                  "swarm_policy_forward_explore", "swarm_policy_last_error")   # include/swarm_policy.h
 LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior",
                   "swarm_legacy_status", "swarm_legacy_last_error")
 
@@ -75,6 +76,8 @@ def load():
     lib.swarm_policy_destroy.argtypes = [vp]; lib.swarm_policy_destroy.restype = None
     lib.swarm_policy_forward.argtypes = [vp, vp, ctypes.c_int64, vp, vp]; lib.swarm_policy_forward.restype = i32
     lib.swarm_policy_forward_bf16.argtypes = [vp, vp, ctypes.c_int64, vp, vp]; lib.swarm_policy_forward_bf16.restype = i32
+    lib.swarm_policy_forward_explore.argtypes = [vp, vp, i32, ctypes.c_int64, vp, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, vp]
+    lib.swarm_policy_forward_explore.restype = i32
     lib.swarm_policy_last_error.argtypes = []; lib.swarm_policy_last_error.restype = ctypes.c_char_p
     lib.swarm_observe.argtypes = [vp, vp]; lib.swarm_observe.restype = i32
     lib.swarm_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]; lib.swarm_step.restype = i32

@@ -175,9 +175,26 @@ class SwarmBatch:
         check(self.lib, self.handle, self.lib.swarm_observe(self.handle, _ptr(obs)))
         return obs
 
-    def step(self, action):
+    def _out_ptrs(self, out):
+        """Caller-owned output tensors (e.g. the slots of a replay ring: the step then writes its transition where it is
+        kept): dict with any of obs [E,N,D] (obs dtype), rew [E,N] f32, done [E,N] uint8, prior [E,N,2] (obs dtype)."""
+        E, N, D = self.n_env, self.n_agents, self.obs_dim
+        want = {"obs": ((E, N, D), self.obs_dtype), "rew": ((E, N), torch.float32), "done": ((E, N), torch.uint8),
+                "prior": ((E, N, 2), self.obs_dtype)}
+        res = {}
+        for k, (shape, dt) in want.items():
+            t = out.get(k)
+            if t is None:
+                continue
+            if t.device != self.device or t.dtype != dt or t.numel() != int(np.prod(shape)) or not t.is_contiguous():
+                raise SwarmError(f"out[{k!r}] must be a contiguous {dt} tensor of {int(np.prod(shape))} elements on {self.device}")
+            res[k] = t
+        return res
+
+    def step(self, action, out=None):
         """action [E, N, 2] float32/float64 device tensor -> (obs [E,N,D], reward [E,N], done [E,N] uint8,
-        a_prior [E,N,2] or None).  Asynchronous on torch's current stream."""
+        a_prior [E,N,2] or None).  Asynchronous on torch's current stream.  out: optional dict of caller-owned output
+        tensors (see _out_ptrs) written instead of the batch's own ping-pong buffers."""
         if action is None:
             if not self.has_llm_action:
                 raise SwarmError("action=None needs a batch created with llm_action=True (agent_strategy 'llm')")
@@ -191,12 +208,17 @@ class SwarmBatch:
             action = action.contiguous()
         self._flip ^= 1
         f = self._flip
+        o = self._out_ptrs(out) if out else {}
+        E, N, D = self.n_env, self.n_agents, self.obs_dim
+        obs = o["obs"].view(E, N, D) if "obs" in o else self._obs[f]
+        rew = o["rew"].view(E, N) if "rew" in o else self._rew[f]
+        done = o["done"].view(E, N) if "done" in o else self._done
+        pri = (o["prior"].view(E, N, 2) if "prior" in o else self._pri[f]) if self.with_prior else None
         self._sync_stream()
         check(self.lib, self.handle,
               self.lib.swarm_step(self.handle, _ptr(action), F64 if (action is None or action.dtype == torch.float64) else F32,
-                                  _ptr(self._obs[f]), _ptr(self._rew[f]), _ptr(self._done),
-                                  _ptr(self._pri[f]) if self.with_prior else None))
-        return self._obs[f], self._rew[f], self._done, (self._pri[f] if self.with_prior else None)
+                                  _ptr(obs), _ptr(rew), _ptr(done), _ptr(pri)))
+        return obs, rew, done, pri
 
     # -- the reference-shaped host outputs (numpy API) -----------------------------------------------------
     def host_views(self):

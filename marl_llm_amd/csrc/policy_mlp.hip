@@ -42,7 +42,18 @@ struct MlpParams {
     const float *b1, *b2, *b3, *b4;        // padded biases (kKP, kKP, kKP, 32)
     int in_dim, act_dim;
     long long rows;
+    // exploration noise of the rollout (agents.py:93-96: action += scale * N(0, 1); clamp to [-1, 1]), fused into the epilogue:
+    // counter-based generator keyed by (seed, step, row), two normals per hash (Box-Muller)
+    float noise_scale;
+    unsigned long long noise_key;      // mix64(seed, step), host-side
 };
+
+__host__ __device__ inline unsigned long long pmix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 
 __device__ __forceinline__ int feat_of(int mt, int reg, int h) { return 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -173,9 +184,29 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
                     const long long row = row0 + 32 * t;
                     if (h == 0 && row < P.rows) {
                         float *y = act + (size_t)row * P.act_dim;
+                        float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (P.noise_scale > 0.0f) {
+                            unsigned long long hk = pmix64(P.noise_key ^ (unsigned long long)row);
+#pragma unroll
+                            for (int k = 0; k < 4; k += 2) {
+                                if (k < P.act_dim) {
+                                    const float u1 = (float)((unsigned)(hk >> 40) + 1u) * 5.9604644775390625e-08f;      // (0, 1]
+                                    const float u2 = (float)((unsigned)(hk >> 16) & 0xFFFFFFu) * 5.9604644775390625e-08f; // [0, 1)
+                                    const float rad = sqrtf(-2.0f * logf(u1));
+                                    float sn, cs;
+                                    sincosf(6.283185307179586f * u2, &sn, &cs);
+                                    z[k] = rad * cs; z[k + 1] = rad * sn;
+                                    hk = pmix64(hk + 0x9E3779B97F4A7C15ull);
+                                }
+                            }
+                        }
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (k < P.act_dim) y[k] = tanhf(o[k]);          // networks.py:43 tanh output
+                            if (k < P.act_dim) {
+                                float v = tanhf(o[k]);                      // networks.py:43 tanh output
+                                if (P.noise_scale > 0.0f) v = fminf(fmaxf(v + P.noise_scale * z[k], -1.0f), 1.0f);
+                                y[k] = v;
+                            }
                     }
                 }
             }
@@ -281,7 +312,7 @@ int swarm_policy_create(const float *w1, const float *b1, const float *w2, const
     const float *bd = reinterpret_cast<const float *>(static_cast<unsigned char *>(p->d_blob) + w_elems * 2);
     p->p.w1 = wd; p->p.w2 = wd + n_hid / 8; p->p.w3 = wd + 2 * n_hid / 8; p->p.w4 = wd + 3 * n_hid / 8;
     p->p.b1 = bd; p->p.b2 = bd + kKP; p->p.b3 = bd + 2 * kKP; p->p.b4 = bd + 3 * kKP;
-    p->p.in_dim = in_dim; p->p.act_dim = act_dim; p->p.rows = 0;
+    p->p.in_dim = in_dim; p->p.act_dim = act_dim; p->p.rows = 0; p->p.noise_scale = 0.0f; p->p.noise_key = 0;
     *out = p;
     return SWARM_POLICY_OK;
 }
@@ -297,7 +328,8 @@ void swarm_policy_destroy(swarm_policy_t *p)
     delete p;
 }
 
-static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int64_t rows, float *act, void *stream)
+static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int64_t rows, float *act, void *stream,
+                          float noise_scale = 0.0f, uint64_t seed = 0, uint64_t step = 0)
 {
     if (!p || !obs || !act || rows < 0) { g_policy_error = "swarm_policy_forward: bad argument"; return SWARM_POLICY_ERR_INVALID; }
     if (in_bf16 && (p->in_dim & 7)) { g_policy_error = "swarm_policy_forward_bf16: in_dim must be a multiple of 8"; return SWARM_POLICY_ERR_INVALID; }
@@ -307,6 +339,8 @@ static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int6
     if (hipSetDevice(p->device) != hipSuccess) { g_policy_error = "swarm_policy_forward: hipSetDevice failed"; return SWARM_POLICY_ERR_HIP; }
     MlpParams q = p->p;
     q.rows = rows;
+    q.noise_scale = noise_scale > 0.0f ? noise_scale : 0.0f;
+    q.noise_key = pmix64(pmix64(seed + 0x9E3779B97F4A7C15ull) ^ (0xD1B54A32D192ED03ull * (step + 1)));
     // one row tile per wave; the two-tile instantiation (SWARM_POLICY_TPW=2, measurement knob) is slower: 98 vs 87 us on
     // 262144 bf16 rows, 118 vs 106 us on fp32 rows -- one wave per SIMD costs more than the halved LDS reads give back
     int tpw = 1;
@@ -343,6 +377,12 @@ int swarm_policy_forward(swarm_policy_t *p, const float *obs, int64_t rows, floa
 int swarm_policy_forward_bf16(swarm_policy_t *p, const void *obs_bf16, int64_t rows, float *act, void *stream)
 {
     return policy_forward(p, obs_bf16, true, rows, act, stream);
+}
+
+int swarm_policy_forward_explore(swarm_policy_t *p, const void *obs, int obs_is_bf16, int64_t rows, float *act,
+                                 float noise_scale, uint64_t seed, uint64_t step, void *stream)
+{
+    return policy_forward(p, obs, obs_is_bf16 != 0, rows, act, stream, noise_scale, seed, step);
 }
 
 }  // extern "C"

@@ -66,19 +66,25 @@ class FusedPolicy:
         self.close()
         self.handle = h
 
-    def __call__(self, obs):
-        """obs [rows, in_dim] float32 or bfloat16 on the device (contiguous) -> actions [rows, act_dim] float32."""
+    def __call__(self, obs, out=None, noise_scale=0.0, seed=0, step=0):
+        """obs [rows, in_dim] float32 or bfloat16 on the device (contiguous) -> actions [rows, act_dim] float32.
+        noise_scale > 0: the exploring actor of agents.py:93-96 in the same launch -- clamp(action + noise_scale * N(0, 1),
+        -1, 1) with a counter-based generator keyed by (seed, step, row).  out: where to write (a contiguous float32
+        tensor of rows * act_dim elements, e.g. a replay-ring slot)."""
         if (obs.dtype not in (torch.float32, torch.bfloat16) or not obs.is_contiguous() or obs.device != self.device
                 or obs.shape[-1] != self.in_dim):
             raise ValueError("FusedPolicy expects a contiguous float32 / bfloat16 [rows, %d] tensor on %s" % (self.in_dim, self.device))
         rows = obs.numel() // self.in_dim
-        out = torch.empty((rows, self.act_dim), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((rows, self.act_dim), dtype=torch.float32, device=self.device)
+        elif (out.dtype != torch.float32 or out.device != self.device or not out.is_contiguous() or out.numel() != rows * self.act_dim):
+            raise ValueError("out must be a contiguous float32 tensor of %d elements on %s" % (rows * self.act_dim, self.device))
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        fwd = self.lib.swarm_policy_forward_bf16 if obs.dtype == torch.bfloat16 else self.lib.swarm_policy_forward
-        rc = fwd(self.handle, obs.data_ptr(), rows, out.data_ptr(), stream)
+        rc = self.lib.swarm_policy_forward_explore(self.handle, obs.data_ptr(), int(obs.dtype == torch.bfloat16), rows, out.data_ptr(),
+                                                   float(noise_scale), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1), stream)
         if rc != 0:
             raise RuntimeError("swarm_policy_forward failed: " + self.lib.swarm_policy_last_error().decode())
-        return out
+        return out.view(rows, self.act_dim)
 
     def close(self):
         if self.handle is not None:
@@ -160,9 +166,23 @@ class ChainedReplay:
         self.K, self.S, self.n = int(n_steps), int(n_steps) + 1, int(rows_per_step)
         z = lambda d, dt=torch.float32: torch.zeros((self.S, self.n, d), dtype=dt, device=device)
         self.obs = z(obs_dim, obs_dtype)
-        self.act, self.act_prior = z(act_dim), z(act_dim)
-        self.rew, self.done = z(1), z(1)
+        # act_prior in the env's output dtype and done as the env's uint8, so that a step can write them in place
+        self.act, self.act_prior = z(act_dim), z(act_dim, obs_dtype)
+        self.rew, self.done = z(1), z(1, torch.uint8)
         self.cur, self.count, self._chained = 0, 0, False
+
+    # zero-copy use (rollout's fused path): the policy writes its action and the env step its outputs straight into the slots
+    def begin_step(self, obs):
+        """Slots of the transition about to be taken: dict(obs_in = observation rows of the current slot (copied from
+        `obs` unless the chain already holds them), act, rew, done, prior, next_obs).  Follow with end_step()."""
+        c, nx = self.cur, (self.cur + 1) % self.S
+        if not self._chained:
+            self.obs[c].copy_(obs.reshape(self.n, -1))
+        return dict(obs_in=self.obs[c], act=self.act[c], rew=self.rew[c], done=self.done[c], prior=self.act_prior[c],
+                    next_obs=self.obs[nx])
+
+    def end_step(self):
+        self.cur, self.count, self._chained = (self.cur + 1) % self.S, min(self.count + 1, self.K), True
 
     def __len__(self):
         return self.count * self.n
@@ -190,11 +210,13 @@ class ChainedReplay:
         j = (self.cur - 1 - back) % self.S
         r = torch.randint(0, self.n, (batch,), device=dev, generator=generator)
         jn = (j + 1) % self.S
-        return self.obs[j, r], self.act[j, r], self.rew[j, r], self.obs[jn, r], self.done[j, r], self.act_prior[j, r]
+        return (self.obs[j, r], self.act[j, r], self.rew[j, r], self.obs[jn, r], self.done[j, r].to(torch.float32),
+                self.act_prior[j, r].to(torch.float32))
 
 
 @torch.no_grad()
-def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, generator=None, host_rng=None):
+def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, generator=None, host_rng=None,
+            track_reward=True, seed=0, step0=0):
     """Run `steps` env steps entirely on the device.
 
     env   : object with step_tensor(action[E,N,2]) -> (obs[E,N,D], rew[E,N], done[E,N], a_prior[E,N,2]|None)
@@ -203,25 +225,48 @@ def rollout(env, policy, steps, obs, replay=None, noise_scale=0.0, epsilon=0.0, 
     The epsilon coin of agents.py:89 is drawn on the HOST (numpy, like the reference's np.random.rand()): a device-side
     draw would cost a host synchronisation every step.  `host_rng`: anything with a .random() method -- the np.random
     module (default), a RandomState or a Generator (np.random.default_rng).
-    Returns (last obs, mean reward per step tensor [steps])."""
+
+    Fused path (policy is a FusedPolicy, replay a ChainedReplay, env a SwarmBatch): TWO launches per step and no copies --
+    the policy kernel adds the exploration noise in its epilogue (counter-based generator keyed by (seed, step0 + t, row))
+    and writes the action into the replay slot; the env step writes next_obs / reward / done / prior into the ring.
+    Everywhere else: the policy's action + torch noise, then `replay.push`.
+    track_reward: also return the mean reward of every step ([steps] tensor; one small reduction per step).
+    Returns (last obs, mean reward per step tensor [steps] or None)."""
     import numpy as np
+    from .batched import SwarmBatch
     step = env.step_tensor if hasattr(env, "step_tensor") else env.step
     E, N, D = obs.shape
-    rews = torch.zeros(steps, device=obs.device)
+    rews = torch.zeros(steps, device=obs.device) if track_reward else None
     coin = host_rng if host_rng is not None else np.random
+    fused = isinstance(policy, FusedPolicy) and isinstance(replay, ChainedReplay) and isinstance(env, SwarmBatch)
     for t in range(steps):
-        x = obs.reshape(E * N, D)
-        if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and isinstance(policy, FusedPolicy)):
-            x = x.float()
-        act = policy(x)
-        if epsilon > 0 and coin.random() < epsilon:                                                      # agents.py:89-91
-            act = torch.rand(act.shape, device=obs.device, generator=generator) * 2 - 1
-        elif noise_scale > 0:                                                                          # agents.py:93-96
-            act = (act + noise_scale * torch.randn(act.shape, device=obs.device, generator=generator)).clamp_(-1, 1)
-        act = act.reshape(E, N, 2)
-        next_obs, rew, done, pri = step(act)
-        if replay is not None:
-            replay.push(obs, act, rew, next_obs, done, pri)
-        rews[t] = rew.mean()
+        explore_uniform = epsilon > 0 and coin.random() < epsilon                                     # agents.py:89-91
+        if fused:
+            sl = replay.begin_step(obs)
+            if explore_uniform:
+                sl["act"].copy_(torch.rand((E * N, policy.act_dim), device=obs.device, generator=generator) * 2 - 1)
+            else:
+                policy(sl["obs_in"], out=sl["act"], noise_scale=noise_scale, seed=seed, step=step0 + t)
+            next_obs, rew, done, pri = env.step(sl["act"].view(E, N, 2),
+                                                out=dict(obs=sl["next_obs"], rew=sl["rew"], done=sl["done"], prior=sl["prior"]))
+            replay.end_step()
+        else:
+            x = obs.reshape(E * N, D)
+            if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and isinstance(policy, FusedPolicy)):
+                x = x.float()
+            if explore_uniform:
+                act = torch.rand((E * N, 2), device=obs.device, generator=generator) * 2 - 1
+            elif isinstance(policy, FusedPolicy):
+                act = policy(x, noise_scale=noise_scale, seed=seed, step=step0 + t)                   # noise in the kernel's epilogue
+            else:
+                act = policy(x)
+                if noise_scale > 0:                                                                    # agents.py:93-96
+                    act = (act + noise_scale * torch.randn(act.shape, device=obs.device, generator=generator)).clamp_(-1, 1)
+            act = act.reshape(E, N, 2)
+            next_obs, rew, done, pri = step(act)
+            if replay is not None:
+                replay.push(obs, act, rew, next_obs, done, pri)
+        if track_reward:
+            rews[t] = rew.mean()
         obs = next_obs
     return obs, rews

@@ -163,3 +163,92 @@ def test_bf16_env_output_and_rollout():
     assert obs2.dtype == torch.bfloat16 and len(rep) == 4 * E * n_a and torch.isfinite(rews).all()
     for x in outs.values():
         x[4].close()
+
+
+def test_in_kernel_exploration_noise_is_standard_normal():
+    """swarm_policy_forward_explore adds noise_scale * N(0, 1) in the kernel's epilogue (agents.py:93-96) from a counter-based
+    generator keyed by (seed, step, row): moments against the normal distribution (and against torch.randn's on the same
+    sample size), reproducibility per key, independence between keys and between the two action components."""
+    import torch
+    from marl_llm_amd.rollout import FusedPolicy, PolicyMLP
+    m = PolicyMLP(192, 2, 180).cuda()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.zero_()                                   # actor output tanh(0) = 0: the action IS the clamped noise
+    f = FusedPolicy(m)
+    rows, scale = 1 << 18, 0.2                          # |scale * z| < 1 up to 5 sigma: the clamp never bites
+    x = torch.randn(rows, 192, device="cuda")
+    a = f(x, noise_scale=scale, seed=7, step=3)
+    b = f(x, noise_scale=scale, seed=7, step=3)
+    c = f(x, noise_scale=scale, seed=7, step=4)
+    d = f(x, noise_scale=scale, seed=8, step=3)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+    assert torch.equal(f(x), torch.zeros_like(a))       # noise_scale = 0: the plain forward
+    z = (a / scale).double()
+    t = torch.randn(rows, 2, device="cuda", dtype=torch.float64)
+    n = z.numel()
+
+    def moments(v):
+        v = v.flatten()
+        mu = v.mean(); s = v.std()
+        return mu.item(), s.item(), (((v - mu) / s) ** 3).mean().item(), (((v - mu) / s) ** 4).mean().item()
+    for got in (moments(z), moments(z[:, 0]), moments(z[:, 1])):
+        assert abs(got[0]) < 5 / n ** 0.5 * 1.5 and abs(got[1] - 1) < 5 / n ** 0.5 * 1.5
+        assert abs(got[2]) < 0.03 and abs(got[3] - 3) < 0.06
+    ref = moments(t)
+    assert abs(ref[2]) < 0.03 and abs(ref[3] - 3) < 0.06                      # the same bars hold for torch.randn
+    corr = lambda u, v: ((u - u.mean()) * (v - v.mean())).mean().item() / (u.std() * v.std()).item()
+    assert abs(corr(z[:, 0], z[:, 1])) < 0.01                                  # the two components of a row
+    assert abs(corr(z.flatten(), (c / scale).double().flatten())) < 0.01       # consecutive steps
+    assert abs(corr(z[:-1, 0], z[1:, 0])) < 0.01                               # neighbouring rows
+    # tails: P(|z| > 3) = 0.0027
+    assert abs((z.abs() > 3).double().mean().item() - 0.0027) < 0.0005
+    # clamp: a large scale saturates at +-1
+    big = f(x, noise_scale=5.0, seed=1, step=1)
+    assert big.abs().max().item() == 1.0
+
+
+def test_fused_rollout_writes_the_ring_in_place(shapes=None):
+    """rollout's fused path (FusedPolicy + ChainedReplay + SwarmBatch): the policy kernel writes the action into the ring
+    slot, the env step writes next_obs / reward / done / prior there -- no push copies.  With the noise off it must hold
+    exactly the transitions of the push-based path."""
+    import torch
+    from marl_llm_amd.batched import SwarmBatch
+    from marl_llm_amd.rollout import ChainedReplay, FusedPolicy, PolicyMLP, rollout
+    from marl_llm_amd.shapes import r_avoid_for, synthetic_shape_set
+    shapes = synthetic_shape_set()
+    E, N, K = 12, 32, 3
+    n = E * N
+    ng_max = max(np.asarray(g).shape[0] for g in shapes["grid_coords"])
+    torch.manual_seed(0)
+    pol = FusedPolicy(PolicyMLP(192, 2, 180).cuda())
+    rings = []
+    for fused in (True, False):
+        sb = SwarmBatch(n_env=E, n_agents=N, n_cells_max=ng_max, r_avoid=r_avoid_for(N, shapes)); sb.set_shapes(shapes)
+        obs = sb.reset(seed=5)
+        ring = ChainedReplay(K, n, sb.obs_dim, 2, sb.device)
+        if fused:
+            obs, rews = rollout(sb, pol, 5, obs, replay=ring)
+        else:
+            class Push:                                   # same ring, but through push(): rollout takes the generic path
+                def push(self, *a):
+                    ring.push(*a)
+            obs, rews = rollout(sb, pol, 5, obs, replay=Push())
+        rings.append((ring, obs.clone(), rews.clone()))
+        sb.close()
+    (a, oa, ra), (b, ob, rb) = rings
+    assert a.cur == b.cur and a.count == b.count == K and torch.equal(oa, ob) and torch.equal(ra, rb)
+    for name in ("obs", "act", "rew", "done", "act_prior"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.obs[a.cur], oa.reshape(n, -1))
+    # with noise: actions differ from the plain forward but stay in [-1, 1]; the same (seed, step0) reproduces the rollout
+    outs = []
+    for rep in range(2):
+        sb = SwarmBatch(n_env=E, n_agents=N, n_cells_max=ng_max, r_avoid=r_avoid_for(N, shapes)); sb.set_shapes(shapes)
+        obs = sb.reset(seed=5)
+        ring = ChainedReplay(K, n, sb.obs_dim, 2, sb.device)
+        obs, _ = rollout(sb, pol, 4, obs, replay=ring, noise_scale=0.1, seed=11, step0=100, track_reward=False)
+        outs.append((ring.act.clone(), obs.clone()))
+        sb.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].abs().max() <= 1 and not torch.equal(outs[0][0], a.act)
