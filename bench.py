@@ -435,12 +435,16 @@ def rollout_numbers(torch, args, device):
         state = {"obs": obs}
 
         def run(k, replay):
-            state["obs"], _ = rollout(sb, pol, k, state["obs"], replay=replay, noise_scale=0.1)
+            # fused path: noise in the policy kernel's epilogue, transition written straight into the ring (two launches / step)
+            state["obs"], _ = rollout(sb, pol, k, state["obs"], replay=replay, noise_scale=0.1, track_reward=False,
+                                      seed=args.seed, step0=state.get("t", 0))
+            state["t"] = state.get("t", 0) + k
 
         for replay, key in ((None, "env_policy_noise_ms"), (rep, "env_policy_noise_replay_ms")):
             run(60, replay); torch.cuda.synchronize()
             t0 = time.perf_counter(); run(steps, replay); torch.cuda.synchronize()
             out[f"{tag}_{key}"] = (time.perf_counter() - t0) / steps * 1e3
+        out[f"{tag}_agent_steps_per_s_with_replay"] = E * n_a / (out[f"{tag}_env_policy_noise_replay_ms"] * 1e-3)
         sb.close()
         del sb, pol, rep
         torch.cuda.empty_cache()

@@ -100,6 +100,11 @@ def main():
     chain16 = ChainedReplay(8, E * n_a, sb.obs_dim, 2, sb.device, obs_dtype=torch.bfloat16)
     t_f16c = timed(lambda k: with_fused(k, rep=chain16))
     print(f"  bf16 rows: + chained replay push        {t_f16c * 1e3:8.3f} ms   {n / t_f16c / 1e6:9.1f} M")
+
+    def fused_ring(k):          # the fused path: in-kernel noise, transition written in place, no per-step reward reduction
+        state["obs"], _ = rollout(sb, fused, k, state["obs"], replay=chain16, noise_scale=0.1, track_reward=False)
+    t_ring16 = timed(fused_ring)
+    print(f"  bf16 rows: fused ring (2 launches/step) {t_ring16 * 1e3:8.3f} ms   {n / t_ring16 / 1e6:9.1f} M")
     sb.close()
 
 
