@@ -445,6 +445,18 @@ def rollout_numbers(torch, args, device):
             t0 = time.perf_counter(); run(steps, replay); torch.cuda.synchronize()
             out[f"{tag}_{key}"] = (time.perf_counter() - t0) / steps * 1e3
         out[f"{tag}_agent_steps_per_s_with_replay"] = E * n_a / (out[f"{tag}_env_policy_noise_replay_ms"] * 1e-3)
+        if tag == "f32_rows":                                          # the actor kernel alone, both arithmetic modes
+            x = state["obs"].reshape(E * n_a, -1)
+            pol3 = FusedPolicy(pol.module, device=sb.device, precision="bf16x3")
+            for nm, f in (("actor_bf16_ms", pol), ("actor_bf16x3_ms", pol3)):
+                for _ in range(10):
+                    f(x)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    f(x)
+                torch.cuda.synchronize()
+                out[nm] = (time.perf_counter() - t0) / steps * 1e3
+            pol3.close()
         sb.close()
         del sb, pol, rep
         torch.cuda.empty_cache()

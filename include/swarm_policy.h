@@ -44,6 +44,14 @@ int  swarm_policy_forward_bf16(swarm_policy_t *p, const void *obs_bf16, int64_t 
 int  swarm_policy_forward_explore(swarm_policy_t *p, const void *obs, int obs_is_bf16, int64_t rows, float *act,
                                   float noise_scale, uint64_t seed, uint64_t step, void *stream);
 
+/* Arithmetic of the forward calls.  SWARM_POLICY_BF16 (default): operands rounded to bfloat16, fp32 sums -- the contract of
+ * torch.autocast(bfloat16), ~4e-2 from the reference's fp32 actor on actions in [-1, 1].  SWARM_POLICY_BF16X3: operands split
+ * into a high and a low bfloat16 part, three MFMAs per product (hi hi + hi lo + lo hi), fp32 sums -- within ~1e-4 of the fp32
+ * actor (networks.py:6-44), about 2.5x the time. */
+#define SWARM_POLICY_BF16   0
+#define SWARM_POLICY_BF16X3 1
+int  swarm_policy_set_precision(swarm_policy_t *p, int precision);
+
 const char *swarm_policy_last_error(void);
 
 #ifdef __cplusplus

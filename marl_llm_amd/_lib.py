@@ -39,7 +39,7 @@ BATCHED_SYMBOLS = ("swarm_abi_version", "swarm_default_config", "swarm_create", 
                    "swarm_step_algorithmic_bytes", "swarm_timer_start", "swarm_timer_stop", "swarm_lattice_envs", "swarm_set_shapes", "swarm_reset", "swarm_get_cells", "swarm_get_shape_index", "swarm_metrics", "swarm_rule_action",
                    "swarm_host_outputs", "swarm_observe_host", "swarm_step_host", "swarm_get_llm_action")
 POLICY_SYMBOLS = ("swarm_policy_create", "swarm_policy_destroy", "swarm_policy_forward", "swarm_policy_forward_bf16",
-                  "swarm_policy_forward_explore", "swarm_policy_last_error")   # include/swarm_policy.h
+                  "swarm_policy_forward_explore", "swarm_policy_set_precision", "swarm_policy_last_error")   # include/swarm_policy.h
 LEGACY_SYMBOLS = ("_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior",
                   "swarm_legacy_status", "swarm_legacy_last_error")
 
@@ -78,6 +78,7 @@ def load():
     lib.swarm_policy_forward_bf16.argtypes = [vp, vp, ctypes.c_int64, vp, vp]; lib.swarm_policy_forward_bf16.restype = i32
     lib.swarm_policy_forward_explore.argtypes = [vp, vp, i32, ctypes.c_int64, vp, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, vp]
     lib.swarm_policy_forward_explore.restype = i32
+    lib.swarm_policy_set_precision.argtypes = [vp, i32]; lib.swarm_policy_set_precision.restype = i32
     lib.swarm_policy_last_error.argtypes = []; lib.swarm_policy_last_error.restype = ctypes.c_char_p
     lib.swarm_observe.argtypes = [vp, vp]; lib.swarm_observe.restype = i32
     lib.swarm_step.argtypes = [vp, vp, i32, vp, vp, vp, vp]; lib.swarm_step.restype = i32

@@ -39,6 +39,7 @@ constexpr int kWaves = 4;
 
 struct MlpParams {
     const bf8 *w1, *w2, *w3, *w4;          // packed fragments: [feature tile][k-step][lane] x 8 bf16
+    const bf8 *l1, *l2, *l3, *l4;          // the same layout, LOW parts w - bf16(w) (precision mode bf16x3 only)
     const float *b1, *b2, *b3, *b4;        // padded biases (kKP, kKP, kKP, 32)
     int in_dim, act_dim;
     long long rows;
@@ -74,8 +75,12 @@ constexpr int kSmemBytes = 2 * kChunkFrags * 64 * 16;                       // 7
 // TPW = row tiles (32 rows each) per wave.  With one tile every MFMA needs its own 1 KB weight-fragment read from LDS (four
 // SIMDs at full MFMA rate would ask for exactly the LDS bandwidth, 128 B/clk); with two tiles each read feeds two MFMAs at
 // the price of ~390 VGPRs, i.e. one wave per SIMD -- measured slower, so TPW = 1 is what runs (see swarm_policy_forward).
-template <bool IN_BF16, int TPW>
-__global__ void __launch_bounds__(64 * kWaves, TPW == 1 ? 2 : 1)
+// X3 ("bf16x3"): every operand is split into a bf16 high part and a bf16 low part (x = hi + lo to 16 significant bits) and a
+// product is three MFMAs, w_hi x_hi + w_hi x_lo + w_lo x_hi, accumulated in fp32 -- the rollout then follows the reference's
+// fp32 actor to ~1e-4 instead of bf16's 4e-2.  The weight stream alternates high and low chunks (same chunk size, same two
+// LDS buffers: twice as many chunk steps); a high chunk meets both activation parts, a low chunk the high part only.
+template <bool IN_BF16, int TPW, bool X3>
+__global__ void __launch_bounds__(64 * kWaves, (TPW == 1 && !X3) ? 2 : 1)
 k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict__ act)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -86,23 +91,30 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
     const bool wave_on = row0 - r < P.rows;                                             // idle waves still stage and take the barriers
 
     bf8 pre[kPre];
-    auto issue = [&](int c) {                                               // chunk c of the weight stream -> registers
-        const bf8 *w = c < 2 ? P.w1 + (size_t)c * kChunkFrags * 64 : c < 4 ? P.w2 + (size_t)(c - 2) * kChunkFrags * 64
-                     : c < 6 ? P.w3 + (size_t)(c - 4) * kChunkFrags * 64 : P.w4;
+    // chunk step cc: X3 interleaves (chunk c, high) and (chunk c, low)
+    constexpr int kSteps = X3 ? 2 * kChunks : kChunks;
+    auto issue = [&](int cc) {                                              // chunk step cc of the weight stream -> registers
+        const int c = X3 ? cc >> 1 : cc;
+        const bool low = X3 && (cc & 1);
+        const bf8 *b1_ = low ? P.l1 : P.w1, *b2_ = low ? P.l2 : P.w2, *b3_ = low ? P.l3 : P.w3, *b4_ = low ? P.l4 : P.w4;
+        const bf8 *w = c < 2 ? b1_ + (size_t)c * kChunkFrags * 64 : c < 4 ? b2_ + (size_t)(c - 2) * kChunkFrags * 64
+                     : c < 6 ? b3_ + (size_t)(c - 4) * kChunkFrags * 64 : b4_;
         const int n = (c < 6 ? kChunkFrags : kKS) * 64;
 #pragma unroll
         for (int k = 0; k < kPre; ++k) { const int q = tid + k * 64 * kWaves; if (q < n) pre[k] = w[q]; }
     };
-    auto commit = [&](int c) {                                              // registers -> LDS buffer of chunk c
+    auto commit = [&](int cc) {                                             // registers -> LDS buffer of chunk step cc
+        const int c = X3 ? cc >> 1 : cc;
         const int n = (c < 6 ? kChunkFrags : kKS) * 64;
 #pragma unroll
-        for (int k = 0; k < kPre; ++k) { const int q = tid + k * 64 * kWaves; if (q < n) buf[c & 1][q] = pre[k]; }
+        for (int k = 0; k < kPre; ++k) { const int q = tid + k * 64 * kWaves; if (q < n) buf[cc & 1][q] = pre[k]; }
     };
 
     issue(0);
     // the 12 B fragments of layer 1, straight from the observation row (natural k order); later `pk` holds the packed
     // activations of the previous layer (k-step = 2 * feature tile + s)
     bf8 pk[TPW][kKS];
+    bf8 pl[X3 ? TPW : 1][X3 ? kKS : 1];                                     // X3: the low parts of the activations
     f16v acc[TPW][kMT];
     if (wave_on) {
 #pragma unroll
@@ -119,13 +131,19 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
 #pragma unroll
                     for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
                     pk[t][ks] = k0 < P.in_dim ? *reinterpret_cast<const bf8 *>(xb + k0) : z;
+                    if constexpr (X3) pl[t][ks] = z;                        // bf16 rows have no low part
                     continue;
                 }
                 float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
                 if (k0 < P.in_dim) lo = *reinterpret_cast<const float4 *>(x + k0);          // in_dim is a multiple of 4
                 if (k0 + 4 < P.in_dim) hi = *reinterpret_cast<const float4 *>(x + k0 + 4);
-                pk[t][ks][0] = (__bf16)lo.x; pk[t][ks][1] = (__bf16)lo.y; pk[t][ks][2] = (__bf16)lo.z; pk[t][ks][3] = (__bf16)lo.w;
-                pk[t][ks][4] = (__bf16)hi.x; pk[t][ks][5] = (__bf16)hi.y; pk[t][ks][6] = (__bf16)hi.z; pk[t][ks][7] = (__bf16)hi.w;
+                const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const __bf16 hj = (__bf16)xv[j];
+                    pk[t][ks][j] = hj;
+                    if constexpr (X3) pl[t][ks][j] = (__bf16)(xv[j] - (float)hj);
+                }
             }
         }
 #pragma unroll
@@ -141,9 +159,12 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
     __syncthreads();
 
 #pragma unroll
-    for (int c = 0; c < kChunks; ++c) {
-        if (c + 1 < kChunks) issue(c + 1);
-        const bf8 *wl = buf[c & 1];
+    for (int cc = 0; cc < kSteps; ++cc) {
+        const int c = X3 ? cc >> 1 : cc;
+        const bool low = X3 && (cc & 1);                                    // this step holds LOW weight parts
+        const bool last_part = !X3 || low;                                  // the chunk's sums are complete after this step
+        if (cc + 1 < kSteps) issue(cc + 1);
+        const bf8 *wl = buf[cc & 1];
         if (wave_on) {
             if (c < 6) {
                 const int half = c & 1;
@@ -153,10 +174,14 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
                     for (int m = 0; m < 3; ++m) {
                         const bf8 a = wl[(m * kKS + ks) * 64 + lane];
 #pragma unroll
-                        for (int t = 0; t < TPW; ++t)
+                        for (int t = 0; t < TPW; ++t) {
                             acc[t][3 * half + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pk[t][ks], acc[t][3 * half + m], 0, 0, 0);
+                            if constexpr (X3) {
+                                if (!low) acc[t][3 * half + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pl[t][ks], acc[t][3 * half + m], 0, 0, 0);
+                            }
+                        }
                     }
-                if (half == 1) {                                            // layer complete: leaky ReLU (slope 0.01, networks.py:40-42), pack
+                if (half == 1 && last_part) {                               // layer complete: leaky ReLU (slope 0.01, networks.py:40-42), pack
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) {
 #pragma unroll
@@ -166,7 +191,10 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) {
                                     const float v = acc[t][kt][8 * s + j];
-                                    pk[t][2 * kt + s][j] = (__bf16)fmaxf(v, 0.01f * v);
+                                    const float r_ = fmaxf(v, 0.01f * v);
+                                    const __bf16 hj = (__bf16)r_;
+                                    pk[t][2 * kt + s][j] = hj;
+                                    if constexpr (X3) pl[t][2 * kt + s][j] = (__bf16)(r_ - (float)hj);
                                 }
 #pragma unroll
                         for (int mt = 0; mt < kMT; ++mt)
@@ -178,9 +206,15 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
                 // output layer: one feature tile; action k is accumulator register k of the lower lane half (row = reg, h = 0)
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
-                    f16v o = acc[t][0];                                     // zeros
+                    f16v o = acc[t][0];                                     // zeros (X3: the high step's sums on the low step)
 #pragma unroll
-                    for (int ks = 0; ks < kKS; ++ks) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks * 64 + lane], pk[t][ks], o, 0, 0, 0);
+                    for (int ks = 0; ks < kKS; ++ks) {
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks * 64 + lane], pk[t][ks], o, 0, 0, 0);
+                        if constexpr (X3) {
+                            if (!low) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks * 64 + lane], pl[t][ks], o, 0, 0, 0);
+                        }
+                    }
+                    if constexpr (X3) { if (!low) { acc[t][0] = o; continue; } }
                     const long long row = row0 + 32 * t;
                     if (h == 0 && row < P.rows) {
                         float *y = act + (size_t)row * P.act_dim;
@@ -211,8 +245,8 @@ k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict
                 }
             }
         }
-        if (c + 1 < kChunks) {
-            commit(c + 1);                                                  // the other buffer: last read in step c - 1, behind the barrier
+        if (cc + 1 < kSteps) {
+            commit(cc + 1);                                                 // the other buffer: last read in step cc - 1, behind the barrier
             __syncthreads();
         }
     }
@@ -233,6 +267,7 @@ thread_local std::string g_policy_error;
 
 struct swarm_policy {
     int device, in_dim, hidden, act_dim;
+    int precision;                 // 0 = bf16 (default), 1 = bf16x3
     void *d_blob;
     MlpParams p;
     bool smem_set;
@@ -261,15 +296,18 @@ int swarm_policy_create(const float *w1, const float *b1, const float *w2, const
     const size_t frag = 64 * 8;                                   // bf16 elements per fragment
     const size_t n_hid = (size_t)kMT * kKS * frag, n_out = (size_t)kKS * frag;
     const size_t w_elems = 3 * n_hid + n_out;
-    const size_t bytes = w_elems * 2 + (3 * kKP + 32) * 4;
+    const size_t bytes = 2 * w_elems * 2 + (3 * kKP + 32) * 4;                // high parts, low parts, biases
     std::vector<unsigned char> blob(bytes, 0);
     uint16_t *wp = reinterpret_cast<uint16_t *>(blob.data());
-    float *bp = reinterpret_cast<float *>(blob.data() + w_elems * 2);
+    uint16_t *lp = wp + w_elems;                                              // low parts: bf16(w - bf16(w)), same layout
+    float *bp = reinterpret_cast<float *>(blob.data() + 2 * w_elems * 2);
+    auto bf16_val = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
     // k index of fragment element j of lane half h in k-step ks: natural for layer 1 (B comes from memory), permuted for
     // the layers whose B operand is the previous accumulator tile
     auto k_nat = [](int ks, int h, int j) { return 16 * ks + 8 * h + j; };
     auto k_acc = [](int ks, int h, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3); };
     auto pack = [&](uint16_t *dst, const float *w, int n_out_feat, int n_in, int tiles, bool natural) {
+        uint16_t *dlo = lp + (dst - wp);
         for (int mt = 0; mt < tiles; ++mt)
             for (int ks = 0; ks < kKS; ++ks)
                 for (int lane = 0; lane < 64; ++lane)
@@ -277,7 +315,9 @@ int swarm_policy_create(const float *w1, const float *b1, const float *w2, const
                         const int o = 32 * mt + (lane & 31), h = lane >> 5;
                         const int k = natural ? k_nat(ks, h, j) : k_acc(ks, h, j);
                         const float v = (o < n_out_feat && k < n_in) ? w[(size_t)o * n_in + k] : 0.0f;   // torch Linear: [out][in]
-                        dst[((size_t)(mt * kKS + ks) * 64 + lane) * 8 + j] = bf16_rne(v);
+                        const size_t q = ((size_t)(mt * kKS + ks) * 64 + lane) * 8 + j;
+                        dst[q] = bf16_rne(v);
+                        dlo[q] = bf16_rne(v - bf16_val(dst[q]));
                     }
     };
     // The padded hidden feature `one` carries the constant 1.0 through the chain: layer 1 produces it (zero weights, bias 1),
@@ -302,6 +342,7 @@ int swarm_policy_create(const float *w1, const float *b1, const float *w2, const
     swarm_policy *p = new (std::nothrow) swarm_policy;
     if (!p) return SWARM_POLICY_ERR_INVALID;
     p->device = device; p->in_dim = in_dim; p->hidden = hidden; p->act_dim = act_dim; p->d_blob = nullptr; p->smem_set = false;
+    p->precision = 0;
     if (hipMalloc(&p->d_blob, bytes) != hipSuccess || hipMemcpy(p->d_blob, blob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
         if (p->d_blob) (void)hipFree(p->d_blob);
         delete p;
@@ -309,8 +350,10 @@ int swarm_policy_create(const float *w1, const float *b1, const float *w2, const
         return SWARM_POLICY_ERR_HIP;
     }
     const bf8 *wd = reinterpret_cast<const bf8 *>(p->d_blob);
-    const float *bd = reinterpret_cast<const float *>(static_cast<unsigned char *>(p->d_blob) + w_elems * 2);
+    const float *bd = reinterpret_cast<const float *>(static_cast<unsigned char *>(p->d_blob) + 2 * w_elems * 2);
     p->p.w1 = wd; p->p.w2 = wd + n_hid / 8; p->p.w3 = wd + 2 * n_hid / 8; p->p.w4 = wd + 3 * n_hid / 8;
+    const bf8 *ld = wd + w_elems / 8;
+    p->p.l1 = ld; p->p.l2 = ld + n_hid / 8; p->p.l3 = ld + 2 * n_hid / 8; p->p.l4 = ld + 3 * n_hid / 8;
     p->p.b1 = bd; p->p.b2 = bd + kKP; p->p.b3 = bd + 2 * kKP; p->p.b4 = bd + 3 * kKP;
     p->p.in_dim = in_dim; p->p.act_dim = act_dim; p->p.rows = 0; p->p.noise_scale = 0.0f; p->p.noise_key = 0;
     *out = p;
@@ -345,27 +388,40 @@ static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int6
     // 262144 bf16 rows, 118 vs 106 us on fp32 rows -- one wave per SIMD costs more than the halved LDS reads give back
     int tpw = 1;
     if (const char *ev = std::getenv("SWARM_POLICY_TPW")) tpw = ev[0] == '2' ? 2 : 1;
+    if (p->precision == 1) tpw = 1;
     const long long per_block = (long long)kWaves * 32 * tpw;
     const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
     if (!p->smem_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
         p->smem_set = true;
     }
     const dim3 g(grid), b(64 * kWaves);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (tpw == 2) {
-        if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 2>), g, b, kSmemBytes, st, q, obs, act);
-        else hipLaunchKernelGGL((k_policy_mlp<false, 2>), g, b, kSmemBytes, st, q, obs, act);
+    if (p->precision == 1) {
+        if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 1, true>), g, b, kSmemBytes, st, q, obs, act);
+        else hipLaunchKernelGGL((k_policy_mlp<false, 1, true>), g, b, kSmemBytes, st, q, obs, act);
+    } else if (tpw == 2) {
+        if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 2, false>), g, b, kSmemBytes, st, q, obs, act);
+        else hipLaunchKernelGGL((k_policy_mlp<false, 2, false>), g, b, kSmemBytes, st, q, obs, act);
     } else {
-        if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 1>), g, b, kSmemBytes, st, q, obs, act);
-        else hipLaunchKernelGGL((k_policy_mlp<false, 1>), g, b, kSmemBytes, st, q, obs, act);
+        if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 1, false>), g, b, kSmemBytes, st, q, obs, act);
+        else hipLaunchKernelGGL((k_policy_mlp<false, 1, false>), g, b, kSmemBytes, st, q, obs, act);
     }
     const hipError_t e = hipGetLastError();
     (void)hipSetDevice(prev);
     if (e != hipSuccess) { g_policy_error = std::string("swarm_policy_forward: ") + hipGetErrorString(e); return SWARM_POLICY_ERR_HIP; }
+    return SWARM_POLICY_OK;
+}
+
+int swarm_policy_set_precision(swarm_policy_t *p, int precision)
+{
+    if (!p || (precision != SWARM_POLICY_BF16 && precision != SWARM_POLICY_BF16X3)) { g_policy_error = "swarm_policy_set_precision: bad argument"; return SWARM_POLICY_ERR_INVALID; }
+    p->precision = precision;
     return SWARM_POLICY_OK;
 }
 

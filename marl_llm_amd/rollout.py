@@ -39,8 +39,14 @@ class FusedPolicy:
     only (rollouts); numerics = torch.autocast(bfloat16) on the module.  Built from a PolicyMLP (or any module with
     fc1..fc4); call `refresh()` after the learner updated the weights.  No CPU path."""
 
-    def __init__(self, module, device="cuda:0"):
+    def __init__(self, module, device="cuda:0", precision="bf16"):
+        """precision: "bf16" (operands rounded to bfloat16: torch.autocast's contract, ~4e-2 from the fp32 module) or "bf16x3"
+        (high + low bfloat16 parts, three MFMAs per product: ~1e-4 from the fp32 module, the reference's actor arithmetic
+        for rollouts that must follow networks.py:6-44 closely)."""
         import ctypes
+        if precision not in ("bf16", "bf16x3"):
+            raise ValueError("precision must be 'bf16' or 'bf16x3'")
+        self.precision = precision
         from . import _lib
         self._ctypes = ctypes
         self.lib = _lib.load()
@@ -65,6 +71,8 @@ class FusedPolicy:
             raise RuntimeError("swarm_policy_create failed: " + self.lib.swarm_policy_last_error().decode())
         self.close()
         self.handle = h
+        if self.lib.swarm_policy_set_precision(self.handle, 1 if self.precision == "bf16x3" else 0) != 0:
+            raise RuntimeError("swarm_policy_set_precision failed: " + self.lib.swarm_policy_last_error().decode())
 
     def __call__(self, obs, out=None, noise_scale=0.0, seed=0, step=0):
         """obs [rows, in_dim] float32 or bfloat16 on the device (contiguous) -> actions [rows, act_dim] float32.

@@ -68,10 +68,26 @@ def test_bench_spawns_its_own_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-spawn"], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    # rank 0's stdout is EXACTLY one line, the JSON: Gloo / RCCL banners and the other ranks' output go to stderr
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks"] == [0, 1] and d["local_ranks"] == [0, 1] and d["max_rank"] == 1.0
+    assert d["per_rank_kernel_us"] == [100.0, 101.0]          # one entry per rank, gathered through dist_util (rank order)
+
+
+def test_bench_fails_fast_when_a_rank_dies():
+    """A rank that exits early must stop the whole run at once with its exit code, not leave rank 0 waiting in a
+    rendezvous until a timeout (bench.py spawn_ranks polls all children)."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-spawn", "--dry-fail-rank", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1000:])
+    assert "rank 1 failed (exit code 3)" in out.stderr and out.stdout.strip() == ""
+    assert time.time() - t0 < 120
 
 
 def test_bench_refuses_a_world_size_mismatch():

@@ -133,6 +133,18 @@ def test_actor_against_the_reference_mlpnetwork():
     y16b = fused(x.to(torch.bfloat16).contiguous()).cpu().numpy()            # bf16 observation rows (rollout mode)
     assert np.abs(y16b - z["Y"]).max() <= 6e-2
     fused.close()
+    # the accurate actor mode: operands split into high + low bf16 parts, three MFMAs per product -- the rollout follows the
+    # reference's fp32 MLPNetwork itself, not a bf16 approximation of it
+    x3 = FusedPolicy(m, device="cuda", precision="bf16x3")
+    y3 = x3(x.contiguous()).cpu().numpy()
+    e3 = np.abs(y3 - z["Y"])
+    assert e3.max() <= 1e-4 and e3.mean() <= 2e-5, (e3.max(), e3.mean())
+    assert np.abs(y3 - y32).max() <= 1e-4
+    # exploration noise and the in-place output work in this mode too
+    out = torch.empty_like(torch.from_numpy(y3)).to("cuda:0")
+    y3n = x3(x.contiguous(), out=out, noise_scale=0.1, seed=3, step=9)
+    assert y3n.data_ptr() == out.data_ptr() and (y3n.cpu().numpy() != y3).any() and y3n.abs().max() <= 1
+    x3.close()
 
 
 def test_replay_against_the_reference_buffer():
