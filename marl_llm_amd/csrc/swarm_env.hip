@@ -1696,61 +1696,55 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         OT2 *out = reinterpret_cast<OT2 *>(obs) + (size_t)blockIdx.x * EPB * n_a * PPR;
         for (int rep = 0, reps = REPS(7); rep < reps; ++rep) {
             FENCE();
-            const int total = rows * HP;
-            // every pair is (minuend - subtrahend) of the same kind of quantity: half 0 = positions, half 1 =
-            // velocities (the sp array is [px | py | vx | vy], so `half` selects the array pair).  Self block: own
-            // value - 0; neighbour k: neighbour's value - own (zero pair without a neighbour, CPP:79-81); target
-            // block: in shape (own - own), else (cell - own) for the position and (0 - own) for the velocity (CPP:136-137).
-            auto head_pair = [&](int r, int q, int half, bool is_tgt, bool is_nei, int nslot) {
-                const int elr = EPB > 1 ? r / n_a : 0;
-                const int tr = elr * NPAD + (r - elr * n_a);
-                const double *sa = sp + half * 2 * AG;
-                const double own_a = sa[tr], own_b = sa[AG + tr];
-                double ma = own_a, mb = own_b, sa_ = 0.0, sb_ = 0.0;            // self block
-                if (is_nei) {
-                    const int j = snei[tr * kNeiStride + nslot];
-                    const int tj = elr * NPAD + (j < 0 ? 0 : j);
-                    const double na = sa[tj], nb_ = sa[AG + tj];
-                    ma = j >= 0 ? na : 0.0; mb = j >= 0 ? nb_ : 0.0;
-                    sa_ = j >= 0 ? own_a : 0.0; sb_ = j >= 0 ? own_b : 0.0;
-                }
-                if (is_tgt) {
-                    const int ncf = sncf[tr];
-                    sa_ = own_a; sb_ = own_b;
-                    if (!(ncf >> 30)) {
-                        ma = 0.0; mb = 0.0;
-                        if (half == 0) { const double2 g = P.cells_xy[(size_t)(blockIdx.x * EPB + elr) * P.ng_max + (ncf & 0xFFFF)]; ma = g.x; mb = g.y; }
-                    }
-                }
-                double a = ma - sa_, b = mb - sb_;
-                if (P.periodic && is_nei && half == 0) wrap_rel(a, b, P.w_half, P.h_half);      // CPP:79 relative position, wrapped
-                OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
-                store_nt(&out[(size_t)r * PPR + q], o);
-            };
-            // split B sits this pass out when there is a prior policy to evaluate (below): that dependent fp64 chain takes
-            // about as long as its share of the head pairs
+            // The head of a row is NB = self + topo + 1 BLOCKS of four values {x, y, vx, vy}: [own state], the neighbours,
+            // the target.  Lane = (row, block): one 16-byte store per lane, eight lanes cover a row's 128-byte head.  Every
+            // value is (minuend - subtrahend): own block own - 0; neighbour k: neighbour - own (zeros without a neighbour,
+            // CPP:79-81; the relative position wrapped when periodic, CPP:79); target: in shape own - own, else cell - own for
+            // the position and 0 - own for the velocity (CPP:136-137).
+            typedef OT OT4 __attribute__((ext_vector_type(4)));
+            const int NB = P.with_self + P.topo + 1;
+            // split B sits this pass out when there is a prior policy to evaluate (above): that dependent fp64 chain takes
+            // about as long as its share of the head blocks
             const bool b_out = WPE > 1 && P.with_prior != 0;
             const int HT = b_out ? T - AG : T;
             const int ps = tid / AG, ps_b = (SB + WPE - (int)(blockIdx.x % WPE)) % WPE;     // physical split index; split B's
             const int htid = b_out ? (ps < ps_b ? ps : ps - 1) * AG + at : tid;
-            if (b_out && sx == SB) {
-                // nothing
-            } else if (HT % HP == 0) {
-                // the usual case (HP = 16): a thread keeps its pair index q for all its rows, so the kind of pair it
-                // produces is decided once, outside the loop
-                const int q = htid % HP, blk = q >> 1, half = q & 1;
-                const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
-                const int nslot = blk - P.with_self;
-                for (int r = htid / HP; r < rows; r += HT / HP) head_pair(r, q, half, is_tgt, is_nei, nslot);
-            } else {
-                const int dr = HT / HP, dq = HT % HP;
-                int r = htid / HP, q = htid % HP;
-                for (int L = htid; L < total; L += HT) {
-                    const int blk = q >> 1, half = q & 1;
-                    const bool is_tgt = q >= HP - 2, is_nei = !is_tgt && !(P.with_self && blk == 0);
-                    head_pair(r, q, half, is_tgt, is_nei, blk - P.with_self);
-                    q += dq; r += dr;
-                    if (q >= HP) { q -= HP; ++r; }
+            if (!(b_out && sx == SB)) {
+                const int total = rows * NB;
+                for (int item = htid; item < total; item += HT) {
+                    const int r = NB == 8 ? item >> 3 : item / NB, blk = item - r * NB;
+                    const int elr = EPB > 1 ? r / n_a : 0;
+                    const int tr = elr * NPAD + (r - elr * n_a);
+                    const double ox = sp[tr], oy = sp[AG + tr], ou = sp[2 * AG + tr], ov = sp[3 * AG + tr];
+                    double mx = ox, my = oy, mu = ou, mv = ov, qx = 0.0, qy = 0.0, qu = 0.0, qv = 0.0;   // own block: own - 0
+                    const bool is_tgt = blk == NB - 1, is_nei = !is_tgt && !(P.with_self && blk == 0);
+                    if (is_nei) {
+                        const int j = snei[tr * kNeiStride + blk - P.with_self];
+                        const int tj = elr * NPAD + (j < 0 ? 0 : j);
+                        const double nx = sp[tj], ny = sp[AG + tj], nu = sp[2 * AG + tj], nv = sp[3 * AG + tj];
+                        const bool has = j >= 0;
+                        mx = has ? nx : 0.0; my = has ? ny : 0.0; mu = has ? nu : 0.0; mv = has ? nv : 0.0;
+                        qx = has ? ox : 0.0; qy = has ? oy : 0.0; qu = has ? ou : 0.0; qv = has ? ov : 0.0;
+                    }
+                    if (is_tgt) {
+                        const int ncf = sncf[tr];
+                        qx = ox; qy = oy; qu = ou; qv = ov;
+                        if (!(ncf >> 30)) {
+                            const double2 g = P.cells_xy[(size_t)(blockIdx.x * EPB + elr) * P.ng_max + (ncf & 0xFFFF)];
+                            mx = g.x; my = g.y; mu = 0.0; mv = 0.0;
+                        }
+                    }
+                    double a = mx - qx, b = my - qy;
+                    if (P.periodic && is_nei) wrap_rel(a, b, P.w_half, P.h_half);
+                    OT2 *dst = out + (size_t)r * PPR + 2 * blk;
+                    if ((PPR & 1) == 0) {                                // rows are a whole number of blocks: 4-value stores stay aligned
+                        const OT4 o = {to_out<OT>(a), to_out<OT>(b), to_out<OT>(mu - qu), to_out<OT>(mv - qv)};
+                        __builtin_nontemporal_store(o, reinterpret_cast<OT4 *>(dst));
+                    } else {                                             // odd list length (non-reference configs)
+                        OT2 o0, o1;
+                        o0.x = to_out<OT>(a); o0.y = to_out<OT>(b); o1.x = to_out<OT>(mu - qu); o1.y = to_out<OT>(mv - qv);
+                        store_nt(dst, o0); store_nt(dst + 1, o1);
+                    }
                 }
             }
         }
