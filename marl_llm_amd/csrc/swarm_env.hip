@@ -86,7 +86,7 @@ struct KP {
     int off_cxyf, off_partc, off_lat, off_cov, off_flag;
     // lattice (row-space) launches only: per-agent frame, per (window row, agent) column masks / first cell index, per-agent
     // row counts, the agent permutation of the list phase, the fp32 reward verdicts, the occupied columns (export only)
-    int off_hdr, off_srow, off_pcr, off_perm, off_rres, off_orow;
+    int off_hdr, off_srow, off_pcr, off_perm, off_rres, off_orow, off_partd;
     float rew_ga_lat, rew_gb_lat;   // guard band of the fp32 reward decision in lattice steps (see swarm_create)
     float rew_thr_k;           // 0.05 / d_sen: the reward's |v| threshold in lattice steps is rew_thr_k * (d_sen / l)
     int lattice;               // every env's cells are a lattice subset whose sensing window is <= 15 rows: row-space path
@@ -291,7 +291,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     unsigned char *pcr = smem + P.off_pcr;                               // [AG][NRC] kept cells per window row
     u64 *covrow = reinterpret_cast<u64 *>(smem + P.off_cov);             // [EPB][64] columns within r_avoid/2 of ANY agent, per lattice row
     unsigned char *perm = smem + P.off_perm;                             // [T/64][64] agent threads in ascending list length (per wave)
-    unsigned char *rres = smem + P.off_rres;                             // [AG] fp32 reward verdict: bit 0 uniform, bit 1 unsure
     unsigned *orow = reinterpret_cast<unsigned *>(smem + P.off_orow);    // [NRC][AG] occupied columns (export launches only)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -989,22 +988,34 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     part_c[sx * AG + at] = bc;
+    double *part_d = reinterpret_cast<double *>(smem + P.off_partd);     // [WPE][AG] (lattice launches)
+    if constexpr (LAT) {
+        // each walking split evaluates the exact distance of ITS candidate here, before the barrier (the gather overlaps the
+        // other waves' walk); the merge behind the barrier then compares values that sit in LDS instead of every split
+        // gathering every candidate
+        if (sx != SB || WPE == 1) {
+            const double2 g = cell64(bc);
+            const double ex = g.x - px, ey = g.y - py;
+            part_d[sx * AG + at] = ex * ex + ey * ey;
+        }
+    }
     STAMP(16);
     EXIT_AT(4);
     __syncthreads();
     STAMP(17);
     // merge the splits' candidates exactly: (d2 in fp64, cell index) lexicographic minimum = first minimum
-    double best = INFINITY, bex = 0.0, bey = 0.0; bc = 0;             // (bex, bey) = nearest cell - own position
+    double best = INFINITY; bc = 0;
     for (int rep = 0, reps = REPS(12); rep < reps; ++rep) {
     FENCE();
     best = INFINITY; bc = 0;
 #pragma unroll
     for (int s = 0; s < WPE; ++s) {
+        if (LAT && WPE > 1 && s == SB) continue;                     // split B does not walk
         const int c = part_c[s * AG + at];
-        const double2 g = cell64(c);
-        const double ex = g.x - px, ey = g.y - py;
-        const double d = ex * ex + ey * ey;
-        if (d < best || (d == best && c < bc)) { best = d; bc = c; bex = ex; bey = ey; }
+        double d;
+        if constexpr (LAT) d = part_d[s * AG + at];
+        else { const double2 g = cell64(c); const double ex = g.x - px, ey = g.y - py; d = ex * ex + ey * ey; }
+        if (d < best || (d == best && c < bc)) { best = d; bc = c; }
     }
     }
     const bool in_shape = act && best < P.c_in[es];                    // CPP:889
@@ -1017,6 +1028,239 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     STAMP(4);
     EXIT_AT(5);
+
+    // ---- observation rows, CPP:102-137,274-306: the rows of this workgroup's environments are contiguous in HBM
+    const int PPR = P.obs_dim >> 1;                  // pairs per row
+    const int HP = 2 * (P.with_self + P.topo) + 2;   // head pairs: agent block + target pos/vel
+    const int envs_here = (P.n_env - blockIdx.x * EPB) < EPB ? (P.n_env - blockIdx.x * EPB) : EPB;
+    const int rows = envs_here * n_a;
+    OT2 *out = reinterpret_cast<OT2 *>(obs) + (size_t)blockIdx.x * EPB * n_a * PPR;
+
+    // ---- prior policy, calculateActionPrior / robotPolicy CPP:1061-1196: a function of the positions, velocities,
+    // neighbour list and nearest cell of THIS observation -- exactly what the reference feeds it at the start of the
+    // next step (ENV:605-624: pre-integration state, previous neighbor_index).  Split B evaluates it here, where all of
+    // that sits in LDS, and leaves it in HBM for the next launch; the other splits write its share of the head pairs.
+    auto prior_policy = [&]() {
+    if (sx == SB && P.with_prior) {
+        double qx = 0.0, qy = 0.0;
+        double lx = 0.0, ly = 0.0;                       // agent_strategy 'llm': the Python twin (ENV:892-940), other repulsion gain
+        {
+            const int ncf = sncf[at];
+            // target: own position when in shape (CPP:889-897) => zero attraction; else the nearest cell
+            double tx = px - px, ty = py - py;
+            if (!(ncf >> 30)) { const double2 g = cell64(ncf & 0xFFFF); tx = g.x - px; ty = g.y - py; }
+            const double dt_ = sqrt(tx * tx + ty * ty);
+            if (dt_ > 0) { qx += P.pk_att * tx / dt_; qy += P.pk_att * ty / dt_; }
+            lx = qx; ly = qy;
+            double avx = 0.0, avy = 0.0; int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < kTopoMax; ++k) {
+                const int j = snei[at * kNeiStride + k];
+                const bool used = j >= 0;
+                const int tj = el * NPAD + (used ? j : 0);
+                const double x = px - sp[tj], y = py - sp[AG + tj];
+                const double d2n = x * x + y * y;
+                if (used && d2n > 0 && d2n < P.c_avoid) {            // 0 < d < r_avoid (CPP:1150-1160), d = sqrt(d2n): sqrt is monotonic
+                    const double d = sqrt(d2n);
+                    const double ux = x / d, uy = y / d;
+                    const double factor = P.pk_rep * (P.r_avoid / d - 1.0);
+                    qx += factor * ux; qy += factor * uy;
+                    if (P.llm) { const double fl = P.pk_llm * (P.r_avoid / d - 1.0); lx += fl * ux; ly += fl * uy; }
+                }
+                if (used) { avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt; }
+            }
+            if (cnt > 0) {
+                avx /= cnt; avy /= cnt;
+                const double sxv = P.pk_ali * (avx - sp[2 * AG + at]), syv = P.pk_ali * (avy - sp[3 * AG + at]);
+                qx += sxv; qy += syv; lx += sxv; ly += syv;
+            }
+        }
+        if (act) {
+            OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
+            reinterpret_cast<OT2 *>(P.prior_next)[(size_t)e * n_a + i] = o;
+            if (P.llm) { double2 u; u.x = clamp_ref(lx, -1.0, 1.0); u.y = clamp_ref(ly, -1.0, 1.0); P.act_next[(size_t)e * n_a + i] = u; }
+        }
+    }
+    };
+
+    auto head_blocks = [&](bool early) {
+        for (int rep = 0, reps = REPS(7); rep < reps; ++rep) {
+            FENCE();
+            // The head of a row is NB = self + topo + 1 BLOCKS of four values {x, y, vx, vy}: [own state], the neighbours,
+            // the target.  Lane = (row, block): one 16-byte store per lane, eight lanes cover a row's 128-byte head.  Every
+            // value is (minuend - subtrahend): own block own - 0; neighbour k: neighbour - own (zeros without a neighbour,
+            // CPP:79-81; the relative position wrapped when periodic, CPP:79); target: in shape own - own, else cell - own for
+            // the position and 0 - own for the velocity (CPP:136-137).
+            typedef OT OT4 __attribute__((ext_vector_type(4)));
+            const int NB = P.with_self + P.topo + 1;
+            // Who writes which blocks.  early == false (generic path): every split but B (busy with the prior policy) takes
+            // items htid, htid + HT, ...  early == true (lattice path): the pass runs BEFORE the barrier that ends the list
+            // phase -- it needs nothing from it -- on the two splits with the shortest lists there (A: five chunks of 64 items
+            // out of eight, C: three), so that the split with the longest lists is not waited for twice.
+            const int total = rows * NB;
+            const bool b_out = WPE > 1 && P.with_prior != 0;
+            const int HT = b_out ? T - AG : T;
+            const int ps = tid / AG, ps_b = (SB + WPE - (int)(blockIdx.x % WPE)) % WPE;     // physical split index; split B's
+            const int htid = b_out ? (ps < ps_b ? ps : ps - 1) * AG + at : tid;
+            const int n_it = early ? (total + 63) >> 6 : (total + HT - 1) / HT;
+            for (int it_ = 0; it_ < n_it; ++it_) {
+                int item;
+                if (early) {
+                    const int c8 = it_ & 7, owner = c8 < 5 ? 0 : 2;
+                    const int k = owner == 0 ? 5 * (it_ >> 3) + c8 : 3 * (it_ >> 3) + c8 - 5;      // the owner's k-th chunk
+                    if (sx != owner || (k % NW) != aw) continue;
+                    item = it_ * 64 + lane;
+                } else {
+                    if (b_out && sx == SB) break;
+                    item = htid + it_ * HT;
+                }
+                if (item < total) {
+                    const int r = NB == 8 ? item >> 3 : item / NB, blk = item - r * NB;
+                    const int elr = EPB > 1 ? r / n_a : 0;
+                    const int tr = elr * NPAD + (r - elr * n_a);
+                    const double ox = sp[tr], oy = sp[AG + tr], ou = sp[2 * AG + tr], ov = sp[3 * AG + tr];
+                    // straight-line code (every lane reads a neighbour slot, the nearest-cell word and that cell; the block kind
+                    // only selects): a branch per kind would put each dependent LDS read / gather behind its own wait
+                    const bool is_tgt = blk == NB - 1, is_nei = !is_tgt && !(P.with_self && blk == 0);
+                    const int nslot = blk - P.with_self;
+                    const int j = snei[tr * kNeiStride + (is_nei ? nslot : 0)];
+                    const int ncf = sncf[tr];
+                    const double2 g = P.cells_xy[(size_t)(blockIdx.x * EPB + elr) * P.ng_max + (ncf & 0xFFFF)];
+                    const int tj = elr * NPAD + (j < 0 ? 0 : j);
+                    const double nx = sp[tj], ny = sp[AG + tj], nu = sp[2 * AG + tj], nv = sp[3 * AG + tj];
+                    const bool has = is_nei && j >= 0, out_t = is_tgt && !(ncf >> 30);
+                    // minuend: neighbour | cell (target, outside the shape: velocity 0) | own; subtrahend: own | 0
+                    const bool zero_m = is_nei && !has;
+                    double mx = has ? nx : (out_t ? g.x : ox), my = has ? ny : (out_t ? g.y : oy);
+                    double mu = has ? nu : (out_t ? 0.0 : ou), mv = has ? nv : (out_t ? 0.0 : ov);
+                    if (zero_m) { mx = 0.0; my = 0.0; mu = 0.0; mv = 0.0; }
+                    const bool sub_own = has || is_tgt;
+                    const double qx = sub_own ? ox : 0.0, qy = sub_own ? oy : 0.0, qu = sub_own ? ou : 0.0, qv = sub_own ? ov : 0.0;
+                    double a = mx - qx, b = my - qy;
+                    if (P.periodic && is_nei) wrap_rel(a, b, P.w_half, P.h_half);
+                    OT2 *dst = out + (size_t)r * PPR + 2 * blk;
+                    if ((PPR & 1) == 0) {                                // rows are a whole number of blocks: 4-value stores stay aligned
+                        const OT4 o = {to_out<OT>(a), to_out<OT>(b), to_out<OT>(mu - qu), to_out<OT>(mv - qv)};
+                        __builtin_nontemporal_store(o, reinterpret_cast<OT4 *>(dst));
+                    } else {                                             // odd list length (non-reference configs)
+                        OT2 o0, o1;
+                        o0.x = to_out<OT>(a); o0.y = to_out<OT>(b); o1.x = to_out<OT>(mu - qu); o1.y = to_out<OT>(mv - qv);
+                        store_nt(dst, o0); store_nt(dst + 1, o1);
+                    }
+                }
+            }
+        }
+    };
+
+    // Exact exploration-reward verdict of ONE agent thread (CPP:529-549), wave-cooperative and called by the whole wave
+    // with wave-uniform arguments: the 64 lanes evaluate one list slot each in fp64 -- psi needs a sqrt and a 12-term
+    // cosine -- and the three sums then run over the lanes' values sequentially in slot order (v_readlane broadcasts), which
+    // is the reference's order of additions.  Rare (the fp32 verdict decides outside its guard band); a lane looping alone
+    // over its list made its workgroup a straggler.  La: agent thread, nL: its list length, eL: its environment.
+    auto exact_uniform = [&](int La, int nL, int eL) -> bool {
+        const double inv_dsen = 1.0 / P.d_sen;
+        const double2 *gcl = P.cells_xy + (size_t)eL * P.ng_max;
+        const double pxl = sp[La], pyl = sp[AG + La];
+        const short *rowl = sidx + (size_t)La * P.g_stride;
+        auto bcast = [](double v, int t) -> double {
+            const u64 b = __builtin_bit_cast(u64, v);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, t);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), t);
+            return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
+        };
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int base = 0; base < nL; base += 64) {
+            const int q = base + lane;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+            if (q < nL) {
+                const int cc = rowl[q];
+                const double2 gq = gcl[cc];
+                const double x = gq.x - pxl, y = gq.y - pyl;
+                const double z = sqrt(x * x + y * y);
+                // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
+                const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
+                t0 = psi * x; t1 = psi * y; t2 = psi;
+            }
+            const int m = nL - base < 64 ? nL - base : 64;
+            for (int t = 0; t < m; ++t) { a0 += bcast(t0, t); a1 += bcast(t1, t); a2 += bcast(t2, t); }
+        }
+        if (a2 == 0) a2 = 1E-8;
+        const double v0 = 1.0 * a0 / a2, v1 = 1.0 * a1 / a2;
+        return sqrt(v0 * v0 + v1 * v1) < 0.05;
+    };
+
+    // The G sensed-cell pairs of the observation rows (CPP:274-291): value = stored cell - own position in f64, rounded once.
+    // own == false (generic path, behind the workgroup barrier that completes every list): the waves deal the rows.
+    // own == true (lattice path): every wave writes the rows of the sixteen agents whose lists IT has just emitted (pw: its
+    // agent permutation) -- all four lanes of an agent sit in one wave, so no workgroup barrier separates list and rows.
+    auto sensed_rows = [&](bool own, const unsigned char *pw) {
+        for (int rep = 0, reps = REPS(8); rep < reps; ++rep) {
+            FENCE();
+            const int Gp = P.g_max;
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
+            // row slot k of this wave -> agent thread tr, environment in the workgroup elr, output row r, "row exists"
+            auto locate = [&](int k, int &tr, int &elr, int &r) -> bool {
+                if (own) {
+                    const int ta = (at & ~63) + pw[sx * 16 + k];
+                    const int ii = NPAD < 64 ? (ta & 63) % NPAD : ta;
+                    elr = NPAD < 64 ? (ta & 63) / NPAD : 0;
+                    tr = ta; r = elr * n_a + ii;
+                    return (blockIdx.x * EPB + elr) < P.n_env && ii < n_a;
+                }
+                r = k;
+                const bool ok = r < rows;
+                const int rq = ok ? r : rows - 1;
+                elr = EPB > 1 ? rq / n_a : 0;
+                tr = elr * NPAD + (rq - elr * n_a);
+                return ok;
+            };
+            if (Gp == 80 && sizeof(OT) <= 4) {
+                // the reference's list length: TWO slots per lane, so every store instruction writes 64 x 16 B (f32) of
+                // consecutive addresses -- half the store instructions of the pair-per-lane form.  A row has 40 two-slot
+                // chunks; 8 rows = 320 chunks = 5 full passes.
+                typedef OT OT4 __attribute__((ext_vector_type(4)));
+                const int ngrp = own ? 2 : (rows + nwv * 8 - 1) / (nwv * 8);
+                for (int g8 = 0; g8 < ngrp; ++g8) {
+#pragma unroll
+                    for (int ps = 0; ps < 5; ++ps) {
+                        const int ch = ps * 64 + lane;                   // 0..319
+                        const int rl = (ch * 205) >> 13;                 // ch / 40 (exact for ch < 320)
+                        const int m = ch - rl * 40;
+                        // straight-line: both gathers of every pass are issued unconditionally (an empty slot reads cell 0
+                        // and stores zeros), so the five passes' loads are in flight together instead of one wait each
+                        int tr, elr, r;
+                        const bool ok = locate(own ? g8 * 8 + rl : (wv + g8 * nwv) * 8 + rl, tr, elr, r);
+                        const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
+                        const double qx = sp[tr], qy = sp[AG + tr];
+                        const int cc = *reinterpret_cast<const int *>(sidx + (size_t)tr * P.g_stride + 2 * m);
+                        const int c0 = (int)(short)(cc & 0xFFFF), c1 = cc >> 16;
+                        const double2 g0 = gr[c0 < 0 ? 0 : c0], g1 = gr[c1 < 0 ? 0 : c1];
+                        const OT z = to_out<OT>(0.0);
+                        const OT a0 = to_out<OT>(g0.x - qx), b0 = to_out<OT>(g0.y - qy);
+                        const OT a1 = to_out<OT>(g1.x - qx), b1 = to_out<OT>(g1.y - qy);
+                        OT4 o = {c0 >= 0 ? a0 : z, c0 >= 0 ? b0 : z, c1 >= 0 ? a1 : z, c1 >= 0 ? b1 : z};
+                        if (ok) __builtin_nontemporal_store(o, reinterpret_cast<OT4 *>(out + (size_t)r * PPR + HP + 2 * m));
+                    }
+                }
+            } else {
+                // any other list length / f64 rows: wave per row, lane = slot
+                const int nrow = own ? 16 : (rows - wv + nwv - 1) / nwv;
+                for (int k = 0; k < nrow; ++k) {
+                    int tr, elr, r;
+                    const bool ok = locate(own ? k : wv + k * nwv, tr, elr, r);
+                    const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
+                    const double qx = sp[tr], qy = sp[AG + tr];
+                    const short *srw = sidx + (size_t)tr * P.g_stride;
+                    for (int q = lane; q < Gp; q += 64) {
+                        const int c = srw[q];
+                        const double2 g = gr[c < 0 ? 0 : c];
+                        OT2 o; o.x = c >= 0 ? to_out<OT>(g.x - qx) : to_out<OT>(0.0); o.y = c >= 0 ? to_out<OT>(g.y - qy) : to_out<OT>(0.0);
+                        if (ok) store_nt(&out[(size_t)r * PPR + HP + q], o);
+                    }
+                }
+            }
+        }
+    };
 
     const int G = P.g_max;
     int n_sel = 0;                                   // length of this agent thread's capped list
@@ -1123,6 +1367,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // below it) and its reward weight psi(u), u = (distance / d_sen)^2 from the LATTICE coordinates -- |v| is invariant
     // under the lattice's rotation, so the sums run in lattice steps and need neither the stored cells nor a list
     // read-back.  The fp32 result only DECIDES outside a guard band; inside it the sums are redone in fp64 below.
+    float qn0 = 0.0f, qn1 = 0.0f, qdn = 0.0f, qrl = 1.0f; int qnk = 0;      // the quad's reward sums / list length / d_sen in steps
     for (int rep = 0, reps = REPS(11); rep < reps; ++rep) {
         FENCE();
         const int sub = lane & 3;
@@ -1232,32 +1477,57 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         };
         if (__any(nk > G)) walk_range(std::true_type{}); else walk_range(std::false_type{});
-        // the quad's partial sums -> every lane of the quad (two DPP exchanges), lane 0 of the quad decides
+        // the quad's partial sums -> every lane of the quad (two DPP exchanges)
         auto quad_sum = [](float v) -> float {
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
             return v;
         };
-        n0 = quad_sum(n0); n1 = quad_sum(n1); dn = quad_sum(dn);
-        if (sub == 0) {
-            const int nsl = nk > G ? G : nk;
-            const float thr = P.rew_thr_k * Rl;                      // 0.05 in lattice steps
-            const float v0f = n0 / dn, v1f = n1 / dn;
-            const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
-            const bool uni = nsl > 0 && vf < thr;
-            const bool uns = nsl > 0 && (P.force_exact || !(dn > 1e-6f) || !(fabsf(vf - thr) > P.rew_ga_lat * (float)nsl / dn + P.rew_gb_lat));
-            rres[ea] = (unsigned char)((uni ? 1 : 0) | (uns ? 2 : 0));
-        }
+        qn0 = quad_sum(n0); qn1 = quad_sum(n1); qdn = quad_sum(dn); qnk = nk; qrl = Rl;
     }
     STAMP(19);
-    __syncthreads();
-    STAMP(6);
     EXIT_AT(9);
-    if (sx == 0) {
-        const int rr = rres[at];
-        const bool has = in_shape && n_sel > 0;
-        uniform = has && (rr & 1) != 0;
-        unsure = has && (rr & 2) != 0;
+    // ---- (R) reward of the quad's agent (CPP:554-556), decided by the quad's first lane right here: everything it needs was
+    // produced by this wave (the list, the sums) or long before (in-shape flag, collision flag).  The fp32 verdict only
+    // DECIDES outside its guard band; an unsure agent is redone exactly by the whole wave.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // this wave's list rows: written above, read below
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const int nsl = qnk > G ? G : qnk;
+        const bool in_a = (sncf[ea] >> 30) != 0;
+        const int ael = NPAD < 64 ? (ea & 63) / NPAD : 0, ai = NPAD < 64 ? (ea & 63) % NPAD : ea;
+        const int ae = blockIdx.x * EPB + ael;
+        const bool lead = (lane & 3) == 0 && ae < P.n_env && ai < n_a;
+        const bool has = lead && in_a && nsl > 0;
+        const float thr = P.rew_thr_k * qrl;                         // 0.05 in lattice steps
+        const float v0f = qn0 / qdn, v1f = qn1 / qdn;
+        const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
+        bool uni = has && vf < thr;
+        const bool uns = has && (P.force_exact || !(qdn > 1e-6f) || !(fabsf(vf - thr) > P.rew_ga_lat * (float)nsl / qdn + P.rew_gb_lat));
+        u64 um = __ballot(uns);
+        while (um != 0) {
+            const int L = __ffsll((unsigned long long)um) - 1;
+            um &= um - 1;
+            const bool res = exact_uniform(__builtin_amdgcn_readlane(ea, L), __builtin_amdgcn_readlane(nsl, L), __builtin_amdgcn_readlane(ae, L));
+            if (lane == L) uni = res;
+        }
+        if (lead) {
+            const size_t oi = (size_t)ae * n_a + ai;
+            if (reward != nullptr) __builtin_nontemporal_store((in_a && !(snei[ea * kNeiStride + kTopoMax] != 0) && uni) ? 1.0f : 0.0f, &reward[oi]);   // CPP:554-556
+            if (done != nullptr) __builtin_nontemporal_store((uint8_t)0, &done[oi]);                                                                     // ENV:480-482
+        }
+    }
+    STAMP(6);
+    EXIT_AT(10);
+    // Work that needs nothing from the list phase: the prior policy on split B, the observation heads on the two splits whose
+    // lists were shortest (A and C); the split with the longest lists (D) goes straight to its rows.
+    prior_policy();
+    if (obs != nullptr) {
+        head_blocks(true);
+        STAMP(9);
+        EXIT_AT(11);
+        sensed_rows(true, perm + (tid >> 6) * 64);
     }
     } else {
     // ---- occupied-cell filter, CPP:144-216: a sensed cell is occupied iff some nearby agent is within
@@ -1542,65 +1812,25 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     }
     }
 
-    if (sx == 0) {
-        const bool has = in_shape && n_sel > 0;
-        (void)has;
-        u64 um = __ballot(unsure);
-        if (um != 0) {
-            const double inv_dsen = 1.0 / P.d_sen;
-            {
-                // exact (CPP:529-549), wave-cooperative: for each unsure agent (rarely more than one per wave) the 64 lanes
-                // evaluate one list slot each in fp64 -- psi needs a sqrt and a 12-term cosine -- and park the three
-                // products in LDS; the sums then run over them sequentially in slot order, which is the reference's
-                // order of additions.  (A lane looping alone over its list made this workgroup a straggler.)
-                // scratch [3][64] doubles per wave: over the (dead) rsum for one wave per split, behind it when the other
-                // waves of this split may still be reading theirs
-                // (lattice launches: over the window-row words, dead since the list phase)
-                double *scr = LAT ? reinterpret_cast<double *>(smem + P.off_srow + aw * 1536)
-                                  : reinterpret_cast<double *>(smem + P.off_cmask + (NW > 1 ? WPE * 3 * AG * 4 + aw * 1536 : 0));
-                while (um != 0) {
-                    const int L = __ffsll((unsigned long long)um) - 1;               // agent thread, wave-uniform
-                    um &= um - 1;
-                    const int nL = __builtin_amdgcn_readlane(n_sel, L);
-                    const int eL = blockIdx.x * EPB + (NPAD < 64 ? L / NPAD : 0);
-                    const double2 *gcl = P.cells_xy + (size_t)eL * P.ng_max;
-                    const int La = (at & ~63) + L;                                  // agent thread of lane L in this wave
-                    const double pxl = sp[La], pyl = sp[AG + La];
-                    const short *rowl = sidx + (size_t)La * P.g_stride;
-                    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-                    for (int base = 0; base < nL; base += 64) {
-                        const int q = base + lane;
-                        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-                        if (q < nL) {
-                            const int cc = rowl[q];
-                            const double2 gq = gcl[cc];
-                            const double x = gq.x - pxl, y = gq.y - pyl;
-                            const double z = sqrt(x * x + y * y);
-                            // _rho_cos_dec(z, 0, d_sen), CPP:1012-1020; z < d_sen holds for every sensed cell
-                            const double psi = z < P.d_sen ? 0.5 * (1.0 + cospi01(z * inv_dsen)) : 0.0;
-                            t0 = psi * x; t1 = psi * y; t2 = psi;
-                        }
-                        scr[lane] = t0; scr[64 + lane] = t1; scr[128 + lane] = t2;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const int m = nL - base < 64 ? nL - base : 64;
-#pragma unroll 8
-                        for (int t = 0; t < m; ++t) { a0 += scr[t]; a1 += scr[64 + t]; a2 += scr[128 + t]; }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    if (a2 == 0) a2 = 1E-8;
-                    const double v0 = 1.0 * a0 / a2, v1 = 1.0 * a1 / a2;
-                    const bool res = sqrt(v0 * v0 + v1 * v1) < 0.05;
-                    if (lane == L) uniform = res;
-                }
+    if constexpr (!LAT) {
+        // generic path: split A combines the splits' fp32 sums (above) and stores the reward
+        if (sx == 0) {
+            u64 um = __ballot(unsure);
+            while (um != 0) {
+                const int L = __ffsll((unsigned long long)um) - 1;               // agent thread, wave-uniform
+                um &= um - 1;
+                const bool res = exact_uniform((at & ~63) + L, __builtin_amdgcn_readlane(n_sel, L), blockIdx.x * EPB + (NPAD < 64 ? L / NPAD : 0));
+                if (lane == L) uniform = res;
+            }
+            if (act) {
+                if (reward != nullptr) __builtin_nontemporal_store((in_shape && !(snei[at * kNeiStride + kTopoMax] != 0) && uniform) ? 1.0f : 0.0f, &reward[(size_t)e * n_a + i]);   // CPP:554-556
+                if (done != nullptr) __builtin_nontemporal_store((uint8_t)0, &done[(size_t)e * n_a + i]);                                                         // ENV:480-482
             }
         }
-        if (act) {
-            if (reward != nullptr) __builtin_nontemporal_store((in_shape && !(snei[at * kNeiStride + kTopoMax] != 0) && uniform) ? 1.0f : 0.0f, &reward[(size_t)e * n_a + i]);   // CPP:554-556
-            if (done != nullptr) __builtin_nontemporal_store((uint8_t)0, &done[(size_t)e * n_a + i]);                                                         // ENV:480-482
-        }
+    }
+    if (P.export_idx) {
+        if constexpr (LAT) __syncthreads();          // export launches only (workgroup-uniform): every wave's lists are complete
+        if (sx == 0) {
         if (P.export_idx && act) {
             const short *row = sidx + (size_t)at * P.g_stride;
             int *es_ = P.exp_sensed + ((size_t)e * n_a + i) * G;
@@ -1636,191 +1866,17 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
             for (; os < O; ++os) eo[os] = -1;
         }
+        }
     }
     STAMP(22);
-    EXIT_AT(10);
-
-    // ---- prior policy, calculateActionPrior / robotPolicy CPP:1061-1196: a function of the positions, velocities,
-    // neighbour list and nearest cell of THIS observation -- exactly what the reference feeds it at the start of the
-    // next step (ENV:605-624: pre-integration state, previous neighbor_index).  Split B evaluates it here, where all of
-    // that sits in LDS, and leaves it in HBM for the next launch; the other splits write its share of the head pairs.
-    if (sx == SB && P.with_prior) {
-        double qx = 0.0, qy = 0.0;
-        double lx = 0.0, ly = 0.0;                       // agent_strategy 'llm': the Python twin (ENV:892-940), other repulsion gain
-        {
-            const int ncf = sncf[at];
-            // target: own position when in shape (CPP:889-897) => zero attraction; else the nearest cell
-            double tx = px - px, ty = py - py;
-            if (!(ncf >> 30)) { const double2 g = cell64(ncf & 0xFFFF); tx = g.x - px; ty = g.y - py; }
-            const double dt_ = sqrt(tx * tx + ty * ty);
-            if (dt_ > 0) { qx += P.pk_att * tx / dt_; qy += P.pk_att * ty / dt_; }
-            lx = qx; ly = qy;
-            double avx = 0.0, avy = 0.0; int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < kTopoMax; ++k) {
-                const int j = snei[at * kNeiStride + k];
-                const bool used = j >= 0;
-                const int tj = el * NPAD + (used ? j : 0);
-                const double x = px - sp[tj], y = py - sp[AG + tj];
-                const double d2n = x * x + y * y;
-                if (used && d2n > 0 && d2n < P.c_avoid) {            // 0 < d < r_avoid (CPP:1150-1160), d = sqrt(d2n): sqrt is monotonic
-                    const double d = sqrt(d2n);
-                    const double ux = x / d, uy = y / d;
-                    const double factor = P.pk_rep * (P.r_avoid / d - 1.0);
-                    qx += factor * ux; qy += factor * uy;
-                    if (P.llm) { const double fl = P.pk_llm * (P.r_avoid / d - 1.0); lx += fl * ux; ly += fl * uy; }
-                }
-                if (used) { avx += sp[2 * AG + tj]; avy += sp[3 * AG + tj]; ++cnt; }
-            }
-            if (cnt > 0) {
-                avx /= cnt; avy /= cnt;
-                const double sxv = P.pk_ali * (avx - sp[2 * AG + at]), syv = P.pk_ali * (avy - sp[3 * AG + at]);
-                qx += sxv; qy += syv; lx += sxv; ly += syv;
-            }
-        }
-        if (act) {
-            OT2 o; o.x = to_out<OT>(clamp_ref(qx, -1.0, 1.0)); o.y = to_out<OT>(clamp_ref(qy, -1.0, 1.0));
-            reinterpret_cast<OT2 *>(P.prior_next)[(size_t)e * n_a + i] = o;
-            if (P.llm) { double2 u; u.x = clamp_ref(lx, -1.0, 1.0); u.y = clamp_ref(ly, -1.0, 1.0); P.act_next[(size_t)e * n_a + i] = u; }
-        }
-    }
-
-    // ---- observation rows, CPP:102-137,274-306, streamed out as (value, value) pairs with consecutive lanes
-    // on consecutive addresses (the rows of this workgroup's environments are contiguous in HBM).  Two passes with
-    // wave-uniform control flow: the 2*(self+topo)+2 head pairs of every row, then the G sensed-cell pairs.
-    if (obs != nullptr) {
-        const int PPR = P.obs_dim >> 1;                  // pairs per row
-        const int HP = 2 * (P.with_self + P.topo) + 2;   // head pairs: agent block + target pos/vel
-        const int envs_here = (P.n_env - blockIdx.x * EPB) < EPB ? (P.n_env - blockIdx.x * EPB) : EPB;
-        const int rows = envs_here * n_a;
-        OT2 *out = reinterpret_cast<OT2 *>(obs) + (size_t)blockIdx.x * EPB * n_a * PPR;
-        for (int rep = 0, reps = REPS(7); rep < reps; ++rep) {
-            FENCE();
-            // The head of a row is NB = self + topo + 1 BLOCKS of four values {x, y, vx, vy}: [own state], the neighbours,
-            // the target.  Lane = (row, block): one 16-byte store per lane, eight lanes cover a row's 128-byte head.  Every
-            // value is (minuend - subtrahend): own block own - 0; neighbour k: neighbour - own (zeros without a neighbour,
-            // CPP:79-81; the relative position wrapped when periodic, CPP:79); target: in shape own - own, else cell - own for
-            // the position and 0 - own for the velocity (CPP:136-137).
-            typedef OT OT4 __attribute__((ext_vector_type(4)));
-            const int NB = P.with_self + P.topo + 1;
-            // split B sits this pass out when there is a prior policy to evaluate (above): that dependent fp64 chain takes
-            // about as long as its share of the head blocks
-            const bool b_out = WPE > 1 && P.with_prior != 0;
-            const int HT = b_out ? T - AG : T;
-            const int ps = tid / AG, ps_b = (SB + WPE - (int)(blockIdx.x % WPE)) % WPE;     // physical split index; split B's
-            const int htid = b_out ? (ps < ps_b ? ps : ps - 1) * AG + at : tid;
-            if (!(b_out && sx == SB)) {
-                const int total = rows * NB;
-                for (int item = htid; item < total; item += HT) {
-                    const int r = NB == 8 ? item >> 3 : item / NB, blk = item - r * NB;
-                    const int elr = EPB > 1 ? r / n_a : 0;
-                    const int tr = elr * NPAD + (r - elr * n_a);
-                    const double ox = sp[tr], oy = sp[AG + tr], ou = sp[2 * AG + tr], ov = sp[3 * AG + tr];
-                    double mx = ox, my = oy, mu = ou, mv = ov, qx = 0.0, qy = 0.0, qu = 0.0, qv = 0.0;   // own block: own - 0
-                    const bool is_tgt = blk == NB - 1, is_nei = !is_tgt && !(P.with_self && blk == 0);
-                    if (is_nei) {
-                        const int j = snei[tr * kNeiStride + blk - P.with_self];
-                        const int tj = elr * NPAD + (j < 0 ? 0 : j);
-                        const double nx = sp[tj], ny = sp[AG + tj], nu = sp[2 * AG + tj], nv = sp[3 * AG + tj];
-                        const bool has = j >= 0;
-                        mx = has ? nx : 0.0; my = has ? ny : 0.0; mu = has ? nu : 0.0; mv = has ? nv : 0.0;
-                        qx = has ? ox : 0.0; qy = has ? oy : 0.0; qu = has ? ou : 0.0; qv = has ? ov : 0.0;
-                    }
-                    if (is_tgt) {
-                        const int ncf = sncf[tr];
-                        qx = ox; qy = oy; qu = ou; qv = ov;
-                        if (!(ncf >> 30)) {
-                            const double2 g = P.cells_xy[(size_t)(blockIdx.x * EPB + elr) * P.ng_max + (ncf & 0xFFFF)];
-                            mx = g.x; my = g.y; mu = 0.0; mv = 0.0;
-                        }
-                    }
-                    double a = mx - qx, b = my - qy;
-                    if (P.periodic && is_nei) wrap_rel(a, b, P.w_half, P.h_half);
-                    OT2 *dst = out + (size_t)r * PPR + 2 * blk;
-                    if ((PPR & 1) == 0) {                                // rows are a whole number of blocks: 4-value stores stay aligned
-                        const OT4 o = {to_out<OT>(a), to_out<OT>(b), to_out<OT>(mu - qu), to_out<OT>(mv - qv)};
-                        __builtin_nontemporal_store(o, reinterpret_cast<OT4 *>(dst));
-                    } else {                                             // odd list length (non-reference configs)
-                        OT2 o0, o1;
-                        o0.x = to_out<OT>(a); o0.y = to_out<OT>(b); o1.x = to_out<OT>(mu - qu); o1.y = to_out<OT>(mv - qv);
-                        store_nt(dst, o0); store_nt(dst + 1, o1);
-                    }
-                }
-            }
-        }
-        STAMP(9);
-        EXIT_AT(11);
-        for (int rep = 0, reps = REPS(8); rep < reps; ++rep) {
-            FENCE();
-            // wave per row: lane = slot, so the row's agent position, cell base and output base are wave-uniform
-            // and each store instruction covers 64 consecutive pairs (512 B / 1 KiB contiguous).  CPP:274-291
-            const int Gp = P.g_max;
-            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
-            if (Gp == 80 && sizeof(OT) <= 4) {
-                // the reference's list length: TWO slots per lane, so every store instruction writes 64 x 16 B (f32) of
-                // consecutive addresses -- half the store instructions of the pair-per-lane form, and the store path, not
-                // the arithmetic, bounds this phase.  A row has 40 two-slot chunks; 8 rows = 320 chunks = 5 full passes.
-                typedef OT OT4 __attribute__((ext_vector_type(4)));
-                for (int r0 = wv * 8; r0 < rows; r0 += nwv * 8) {
-#pragma unroll
-                    for (int ps = 0; ps < 5; ++ps) {
-                        const int ch = ps * 64 + lane;                   // 0..319
-                        const int rl = (ch * 205) >> 13;                 // ch / 40 (exact for ch < 320)
-                        const int m = ch - rl * 40;
-                        const int r = r0 + rl;
-                        if (r < rows) {
-                            const int elr = EPB > 1 ? r / n_a : 0;
-                            const int tr = elr * NPAD + (r - elr * n_a);
-                            const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
-                            const double qx = sp[tr], qy = sp[AG + tr];
-                            const int cc = *reinterpret_cast<const int *>(sidx + (size_t)tr * P.g_stride + 2 * m);
-                            const int c0 = (int)(short)(cc & 0xFFFF), c1 = cc >> 16;
-                            double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
-                            if (c0 >= 0) { const double2 g = gr[c0]; a0 = g.x - qx; b0 = g.y - qy; }
-                            if (c1 >= 0) { const double2 g = gr[c1]; a1 = g.x - qx; b1 = g.y - qy; }
-                            OT4 o = {to_out<OT>(a0), to_out<OT>(b0), to_out<OT>(a1), to_out<OT>(b1)};
-                            __builtin_nontemporal_store(o, reinterpret_cast<OT4 *>(out + (size_t)r * PPR + HP + 2 * m));
-                        }
-                    }
-                }
-            } else {
-            const int nfull = Gp >> 6, tail = Gp & 63;
-            for (int r = wv; r < rows; r += nwv) {
-                const int elr = EPB > 1 ? r / n_a : 0;
-                const int tr = elr * NPAD + (r - elr * n_a);
-                const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
-                const double qx = sp[tr], qy = sp[AG + tr];
-                const short *srow = sidx + (size_t)tr * P.g_stride;
-                OT2 *orow = out + (size_t)r * PPR + HP;
-                for (int ch = 0; ch < nfull; ++ch) {
-                    const int q = ch * 64 + lane;
-                    const int c = srow[q];
-                    double a = 0.0, b = 0.0;
-                    if (c >= 0) { const double2 g = gr[c]; a = g.x - qx; b = g.y - qy; }
-                    OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
-                    store_nt(&orow[q], o);
-                }
-            }
-            if (tail) {                                   // the last (G mod 64) slots: several rows per wave pass
-                int tp = 1;
-                while (tp < tail) tp <<= 1;
-                const int rpw = 64 / tp;                  // rows per wave pass
-                const int sub = lane / tp, q = nfull * 64 + (lane & (tp - 1));
-                for (int r0 = wv * rpw; r0 < rows; r0 += nwv * rpw) {
-                    const int r = r0 + sub;
-                    if (r < rows && q < Gp) {
-                        const int elr = EPB > 1 ? r / n_a : 0;
-                        const int tr = elr * NPAD + (r - elr * n_a);
-                        const double2 *gr = P.cells_xy + (size_t)(blockIdx.x * EPB + elr) * P.ng_max;
-                        const int c = sidx[(size_t)tr * P.g_stride + q];
-                        double a = 0.0, b = 0.0;
-                        if (c >= 0) { const double2 g = gr[c]; a = g.x - sp[tr]; b = g.y - sp[AG + tr]; }
-                        OT2 o; o.x = to_out<OT>(a); o.y = to_out<OT>(b);
-                        store_nt(&out[(size_t)r * PPR + HP + q], o);
-                    }
-                }
-            }
-            }
+    if constexpr (!LAT) {
+        EXIT_AT(10);
+        prior_policy();
+        if (obs != nullptr) {
+            head_blocks(false);
+            STAMP(9);
+            EXIT_AT(11);
+            sensed_rows(false, nullptr);
         }
     }
     STAMP(7);
@@ -2344,6 +2400,7 @@ void layout_t(KP &k)
         k.off_pcr = take((size_t)AG * NRC);
         k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, pm_bytes));      // sidx | pm
         k.off_partc = take((size_t)WPE * AG * 4);                             // nearest-cell candidates | partial ranks
+        k.off_partd = take((size_t)WPE * AG * 8);                             // their exact squared distances
         k.off_lat = take((size_t)EPB * 64 * (8 + 2));
         k.off_cov = take((size_t)EPB * 64 * 8);
         k.off_flag = take((size_t)AG * 4);
@@ -2374,7 +2431,7 @@ void layout_t(KP &k)
     k.off_cxyf = take((size_t)EPB * k.cxq_stride * 4);   // fp32 cell copy of the generic scan
     k.smem_generic = (int)off;
     k.smem_lat = k.smem_lat_export = 0;
-    k.off_hdr = k.off_srow = k.off_pcr = k.off_perm = k.off_rres = k.off_orow = 0;
+    k.off_hdr = k.off_srow = k.off_pcr = k.off_perm = k.off_rres = k.off_orow = k.off_partd = 0;
 }
 
 void layout(KP &k, int npad)
