@@ -163,6 +163,29 @@ __device__ __forceinline__ unsigned shl1_or_mask(unsigned acc, unsigned long lon
     return acc;
 }
 
+// The pair pass's five threshold tests of one (i, j) pair in ONE asm block: all compares first, then all add-with-carry
+// accumulations (acc = 2 acc + test).  The compare that feeds an accumulation is at least four instructions ahead of it, so
+// the VALU-writes-SGPR -> VALU-reads-it hazard (two wait states) is covered by the block's own instructions: no s_nop at all
+// (shl1_or_mask pays one per test).  d2u: un-wrapped squared distance (nearby / exception band / contact), d2: wrapped
+// (candidates, close candidates).
+__device__ __forceinline__ void pair_tests5(double d2u, double d2, double c_nb, double c_hi, double c_ht, double c_cd, double c_c1,
+                                            unsigned &nb, unsigned &hi, unsigned &ht, unsigned &cd, unsigned &c1)
+{
+    unsigned long long m0, m1, m2, m3, m4;
+    asm("v_cmp_lt_f64_e64 %5, %10, %12\n\t"
+        "v_cmp_lt_f64_e64 %6, %10, %13\n\t"
+        "v_cmp_lt_f64_e64 %7, %10, %14\n\t"
+        "v_cmp_lt_f64_e64 %8, %11, %15\n\t"
+        "v_cmp_lt_f64_e64 %9, %11, %16\n\t"
+        "v_addc_co_u32_e64 %0, %5, %0, %0, %5\n\t"
+        "v_addc_co_u32_e64 %1, %6, %1, %1, %6\n\t"
+        "v_addc_co_u32_e64 %2, %7, %2, %2, %7\n\t"
+        "v_addc_co_u32_e64 %3, %8, %3, %3, %8\n\t"
+        "v_addc_co_u32_e64 %4, %9, %4, %4, %9"
+        : "+v"(nb), "+v"(hi), "+v"(ht), "+v"(cd), "+v"(c1), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4)
+        : "v"(d2u), "v"(d2), "s"(c_nb), "s"(c_hi), "s"(c_ht), "s"(c_cd), "s"(c_c1));
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
 template <typename F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
@@ -210,7 +233,8 @@ template <int NPAD> struct Geo {
 #endif
     // waves per SIMD the register allocation aims for: six 4-wave workgroups per CU for N <= 64 (26.6 KB of LDS each in
     // lattice mode); the N > 64 instantiations would spill at that budget
-    static constexpr int WPS = NPAD <= 64 ? SWARM_WPS : 1;
+    // (several environments per wavefront, N < 64: a few more live values -- five waves per SIMD rather than a spill)
+    static constexpr int WPS = NPAD == 64 ? SWARM_WPS : (NPAD < 64 ? 5 : 1);
 };
 
 constexpr double kSentinel = 1.0e200;     // coordinates of padding cells: d2 overflows to +inf
@@ -546,13 +570,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 for (int q = 0; q < JQ; ++q) {
                     double rx = qx[q] - px, ry = qy[q] - py;
                     const double d2u = rx * rx + ry * ry;
-                    nb = shl1_or_mask(nb, __ballot(d2u < P.c_near));
-                    a_hi = shl1_or_mask(a_hi, __ballot(d2u < P.c_near_hi));
-                    ht = shl1_or_mask(ht, __ballot(d2u < P.c_ball));                                  // contact pairs of the NEXT step (ENV:442-457)
                     double d2 = d2u;
                     if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                    cd = shl1_or_mask(cd, __ballot(d2 < P.c_sen));
-                    c1 = shl1_or_mask(c1, __ballot(d2 < P.c_close));
+                    // nearby (CPP:161), its exception band, contact pairs of the NEXT step (ENV:442-457) on the un-wrapped
+                    // distance; candidates (CPP:658) and close candidates on the wrapped one
+                    pair_tests5(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, nb, a_hi, ht, cd, c1);
                     if constexpr (NW > 2) c2 = shl1_or_mask(c2, __ballot(d2 < P.c_close2));           // wider pre-selection ring (N > 128: pays there)
                 }
                 exc = exc || (a_hi != nb);             // some agent is not "nearby" by a hair (see the occupied-cell filter)
@@ -1524,7 +1546,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // lists were shortest (A and C); the split with the longest lists (D) goes straight to its rows.
     prior_policy();
     if (obs != nullptr) {
-        head_blocks(true);
+        head_blocks(NW == 1);                        // (N > 64: dealt over all splits but B -- the list phase is not the long pole there)
         STAMP(9);
         EXIT_AT(11);
         sensed_rows(true, perm + (tid >> 6) * 64);

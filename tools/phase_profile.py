@@ -23,10 +23,10 @@ from marl_llm_amd.synth import synthetic_batch
 # (lattice / row-space kernel: the synthetic and the reference's shapes; the generic scan keeps the round-2 stamp points)
 ORDER = [(0, "start"), (1, "prologue loads + barrier"), (2, "forces | prior, integrate, 2 barriers"),
          (14, "pair-mask loop"), (15, "pair masks: LDS exchange + barrier"), (3, "ordered insertion (B only)"),
-         (16, "lattice walk (not B)"), (17, "barrier after walk"), (4, "nearest merge (gathers)"),
+         (16, "lattice walk (not B)"), (17, "barrier after walk"), (4, "nearest merge (LDS)"),
          (5, "kept rows + counts + list fill + barrier"), (18, "rank by list length + barrier"),
-         (19, "list emission + reward sums (quads)"), (6, "barrier after emission"),
-         (22, "reward combine + stores (A only)"), (9, "obs head pairs"), (7, "obs sensed pairs")]
+         (19, "list emission + reward sums (quads)"), (6, "reward verdict + store (in-wave)"),
+         (9, "prior (B) | obs heads (A, C)"), (7, "obs rows of the wave's own 16 agents")]
 
 
 def main():
