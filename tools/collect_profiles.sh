@@ -29,15 +29,18 @@ kt n64_e32768 --envs 32768 --steps 50
 kt scatter --state scatter
 echo "kernel stats done"
 CSVS=""
-for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
+for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
+         "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32" \
+         "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_LDS_ATOMIC" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   T=$(echo $G | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $G -d $OUT/pmc_$T -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 > /dev/null 2>$OUT/pmc_$T.log
+  rocprofv3 --pmc $G -d $OUT/pmc_$T -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 --prewarm-ms 0 > /dev/null 2>$OUT/pmc_$T.log
   F=$(find $OUT/pmc_$T -name '*counter_collection.csv' | head -1)
   [ -n "$F" ] && CSVS="$CSVS $F"
   echo "pmc pass $T done"
 done
 python3 $R/tools/pmc_summary.py $OUT/final_pmc_summary.json 20 "assembly env, 64 agents x 4096 envs per GPU, assembled state" $CSVS > $OUT/pmc_print.txt
 rm -rf $OUT/pmc_*/
+python3 $R/tools/phase_profile.py 64 4096 > $OUT/per_role_stamps.txt 2>&1      # needs marl_llm_amd/lib/libswarmenv_stamps.so (build_lib(stamps=True))
 python3 $R/tools/ablate.py --cumulative > $OUT/cumulative_time.txt 2>&1
 echo "cumulative time done"
 export ABLATE_STEPS=10
@@ -45,6 +48,9 @@ rocprofv3 --pmc SQ_INSTS_VALU -d $OUT/cumpmc -o p --output-format csv -- python3
 python3 $R/tools/ablate_pmc_cum.py $(find $OUT/cumpmc -name "*counter_collection.csv" | head -1) 10 > $OUT/cumulative_valu.txt
 rm -rf $OUT/cumpmc
 echo "cumulative valu done"
+python3 $R/tools/rollout_bench.py > $OUT/rollout_bench_n64_e4096.txt 2>&1
+python3 $R/tools/stress_consistency.py > $OUT/stress_consistency.txt 2>&1
+tail -1 $OUT/stress_consistency.txt
 cd $R && python3 bench.py --gpus 2 --rehearse-one-gpu --steps 20 --warmup 5 --envs 512 --no-other-configs > $OUT/rehearse_gpus2_one_gpu.json 2> $OUT/rehearse.err
 cat $OUT/rehearse_gpus2_one_gpu.json | cut -c1-300
 ls $OUT

@@ -24,6 +24,7 @@ for k, v in sorted(vals.items()):
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     res["_traffic_bytes_per_launch"] = (2 * res["FETCH_SIZE"]["mean"] + res["WRITE_SIZE"]["mean"]) * 1024
 res["_workload"] = workload
+res["_n_env"] = 4096
 import hashlib, os
 res["_source_sha256"] = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "marl_llm_amd", "csrc", "swarm_env.hip"), "rb").read()).hexdigest()[:16]
 res["_note"] = ("rocprofv3 --pmc, one counter group per pass, last %d launches of k_env<64,float,true> in `python bench.py "
