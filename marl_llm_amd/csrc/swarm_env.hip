@@ -99,7 +99,7 @@ struct KP {
     double bx0, by1, bx2, by3, w_half, h_half;
     double *p, *dp;
     int *nei, *near_cell, *in_flag;
-    unsigned long long *hit;   // [E][N][NW]: agents overlapping agent i in the CURRENT state (contact pairs of the next step)
+    double2 *sf_next;          // [E][N]: contact-spring force on agent i in the CURRENT state = the force term of the next step
     const double *cells;       // [E][2][ng_max] (the ABI's layout)
     const double2 *cells_xy;   // [E][ng_max] (x, y) interleaved copy: one 16-byte gather per cell
     const int *n_g;
@@ -363,16 +363,13 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const size_t sbase = (size_t)es * 2 * n_a;
     double px = __builtin_nan(""), py = __builtin_nan(""), vx = 0.0, vy = 0.0;   // inactive lanes: NaN positions,
     double ax = 0.0, ay = 0.0;                                                    // every comparison is false
-    u64 hit0[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) hit0[w] = 0;
+    double sf0x = 0.0, sf0y = 0.0;
     OT2 pri_now; pri_now.x = to_out<OT>(0.0); pri_now.y = to_out<OT>(0.0);
     const bool copy_prior = DO_STEP && P.with_prior && a_prior != nullptr;
     if (sx == 0 && act) {
-        if (DO_STEP) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) hit0[w] = P.hit[((size_t)e * n_a + i) * NW + w];
-        }
+        // the contact-spring force of THIS step (ENV:442-457 + CPP:735-815) is a function of the pre-integration positions
+        // only: the previous pass evaluated it on exactly these positions, off its critical path, and left it in HBM
+        if (DO_STEP) { const double2 sfl = P.sf_next[(size_t)e * n_a + i]; sf0x = sfl.x; sf0y = sfl.y; }
         px = P.p[sbase + i]; py = P.p[sbase + n_a + i];
         vx = P.dp[sbase + i]; vy = P.dp[sbase + n_a + i];
         if (DO_STEP) {
@@ -435,40 +432,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     auto forces_integrate = [&]() {
         for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
             FENCE();
-            // ---- ball-to-ball contact spring: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all).
-            // Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped when
-            // periodic), d_center un-wrapped for every pair the reference evaluates (its numpy wrap only touches
-            // agent 0's row, which the i>j loop never reads).  Summed over k in index order.
-            double sfx = 0.0, sfy = 0.0;
-            {
-                // pass A (branch-free, unrolled): which agents k overlap agent i (centre distance < 0.07)?
-                // lanes >= n_a hold NaN positions and never compare true.
-                constexpr int KN = NPAD < 64 ? NPAD : 64;
-                const double *spx = sp + el * NPAD, *spy = sp + AG + el * NPAD;
-                // which agents k overlap agent i (centre distance < 2 size_a)?  The previous observation pass evaluated exactly
-                // this test on exactly these positions (its post-integration state is this step's pre-integration state)
-                // and left the masks in HBM.
-                u64 hit[NW];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) hit[w] = hit0[w];
-                // pass B: the colliding pairs in ascending k (the reference's summation order, CPP:799-807)
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    u64 h = hit[w];
-                    while (h) {
-                        const int kk = __ffsll((unsigned long long)h) - 1;
-                        h &= h - 1;
-                        const double dx = spx[w * 64 + kk] - px, dy = spy[w * 64 + kk] - py;
-                        const double dc = sqrt(dx * dx + dy * dy);
-                        const double de = fabs(dc - P.size2);
-                        double wx = dx, wy = dy;
-                        if (P.periodic) wrap_rel(wx, wy, P.w_half, P.h_half);
-                        const double ux = wx / dc, uy = wy / dc;
-                        sfx += 1.0 * de * P.k_ball * (-ux);
-                        sfy += 1.0 * de * P.k_ball * (-uy);
-                    }
-                }
-            }
+            const double sfx = sf0x, sfy = sf0y;                            // contact spring: evaluated by the previous pass (below)
             STAMP(8);
             double Fx = 1 * ax + sfx, Fy = 1 * ay + sfy;                       // ENV:638,640
             if (P.boundary) {                                                   // CPP:817-855, ENV:515-518
@@ -512,10 +476,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // old positions (written above) before the reads below
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            STAMP(11);                                                    // (diagnostic builds: the state / action loads have landed)
             forces_integrate();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             publish_new_state();
+            STAMP(12);
         }
         __syncthreads();
         STAMP(1);
@@ -546,7 +512,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // every split evaluates 1/WPE of the agents j of each 64-agent group (branch-free, unrolled); the partial masks
     // are OR-combined through LDS so that every lane ends up with its complete "nearby" masks (split B also with the
     // candidate masks)
-    u64 nearbyN[NW], candN[NW], cand1N[NW], cand2N[NW];
+    u64 nearbyN[NW], candN[NW], cand1N[NW], cand2N[NW], hitN[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) hitN[w] = 0;
     {
         constexpr int JQ = JN / WPE;                  // agents j per split and 64-agent group
         static_assert(JQ * WPE == JN && JQ <= 32, "pair pass: JN must split evenly into <= 32 agents per split");
@@ -611,11 +579,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 #pragma unroll
                 for (int q = 0; q < WPE; ++q) { candN[0] |= pm[(q * PMK + 1) * AG + at]; cand1N[0] |= pm[(q * PMK + 2) * AG + at]; }
             }
-            if (sx == 0 && act) {
-                u64 hh = 0;
+            if (sx == SB) {
 #pragma unroll
-                for (int q = 0; q < WPE; ++q) hh |= pm[(q * PMK + 3) * AG + at];
-                P.hit[(size_t)e * n_a + i] = hh & ~(1ull << i);               // k != i
+                for (int q = 0; q < WPE; ++q) hitN[0] |= pm[(q * PMK + 3) * AG + at];
+                hitN[0] &= ~(1ull << i);                                       // k != i
             }
         } else {
             __syncthreads();
@@ -624,12 +591,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 nearbyN[w] = pm[(0 * NW + w) * AG + at]; candN[w] = 0; cand1N[w] = 0; cand2N[w] = 0;
                 if (sx == SB) { candN[w] = pm[(1 * NW + w) * AG + at]; cand1N[w] = pm[(2 * NW + w) * AG + at]; cand2N[w] = pm[(4 * NW + w) * AG + at]; }
             }
-            if (sx == 0 && act) {
+            if (sx == SB) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    u64 hh = pm[(3 * NW + w) * AG + at];
-                    if (w == (i >> 6)) hh &= ~(1ull << (i & 63));             // k != i
-                    P.hit[((size_t)e * n_a + i) * NW + w] = hh;
+                    hitN[w] = pm[(3 * NW + w) * AG + at];
+                    if (w == (i >> 6)) hitN[w] &= ~(1ull << (i & 63));         // k != i
                 }
             }
         }
@@ -754,6 +720,35 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         // sorted, and the nearest candidate is always listed)
         collision = dmin < P.c_avoid;
         snei[at * kNeiStride + kTopoMax] = (short)(collision ? 1 : 0);
+    }
+    if (sx == SB) {
+        // ---- ball-to-ball contact spring of the NEXT step: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all), on the
+        // positions just published.  Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped
+        // when periodic), d_center un-wrapped for every pair the reference evaluates (its numpy wrap only touches agent 0's
+        // row, which the i>j loop never reads); summed over k in index order (CPP:799-807).  The colliding pairs (centre
+        // distance < 2 size_a) are the contact masks of the pair pass.  Split B has the time: the other splits walk.
+        double sfx = 0.0, sfy = 0.0;
+        for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
+            FENCE();
+            sfx = 0.0; sfy = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                u64 h = hitN[w];
+                while (h) {
+                    const int kk = __ffsll((unsigned long long)h) - 1;
+                    h &= h - 1;
+                    const double dx = spx[w * 64 + kk] - px, dy = spy[w * 64 + kk] - py;
+                    const double dc = sqrt(dx * dx + dy * dy);
+                    const double de = fabs(dc - P.size2);
+                    double wx = dx, wy = dy;
+                    if (P.periodic) wrap_rel(wx, wy, P.w_half, P.h_half);
+                    const double ux = wx / dc, uy = wy / dc;
+                    sfx += 1.0 * de * P.k_ball * (-ux);
+                    sfy += 1.0 * de * P.k_ball * (-uy);
+                }
+            }
+        }
+        if (act) P.sf_next[(size_t)e * n_a + i] = make_double2(sfx, sfy);
     }
     STAMP(3);
     EXIT_AT(3);
@@ -2287,7 +2282,7 @@ struct swarm_env {
     std::vector<int> lat_ncols;
     bool lattice_disabled;
     int *d_nei, *d_near, *d_inflag, *d_ng, *d_exp_sensed, *d_exp_occ;
-    unsigned long long *d_hit;
+    double2 *d_sf;
     void *d_prior;
     double2 *d_act_next;           // [E][N] the 'llm' strategy's next action (cfg.llm_action)
     // reference-shaped host I/O (swarm_step_host): library-owned step outputs on the device, the export block on the
@@ -2608,7 +2603,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->lat_R.assign((size_t)cfg->n_env, 0.0f); h->lat_Rc.assign((size_t)cfg->n_env, 0.0f);
     h->lat_ncols.assign((size_t)cfg->n_env, 0);
     h->lattice_disabled = (cfg->debug_flags & 2) != 0;
-    h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr; h->d_hit = nullptr; h->d_prior = nullptr;
+    h->d_nei = h->d_near = h->d_inflag = h->d_ng = h->d_exp_sensed = h->d_exp_occ = nullptr; h->d_sf = nullptr; h->d_prior = nullptr;
     h->d_act_next = nullptr;
     h->d_io_obs = h->d_io_prior = nullptr; h->d_io_rew = nullptr; h->d_io_done = nullptr;
     h->d_io_block = nullptr; h->h_io_block[0] = h->h_io_block[1] = nullptr; h->h_io_action = h->d_io_action = nullptr; h->io_block_bytes = 0;
@@ -2697,7 +2692,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     if (cfg->llm_action) alloc((void **)&h->d_act_next, E * N * 16);
     alloc((void **)&h->d_lat, E * sizeof(LatEnv));
     alloc((void **)&h->d_nei, E * N * (size_t)k.topo * 4); alloc((void **)&h->d_near, E * N * 4);
-    alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_hit, E * N * 8 * (size_t)std::max(1, h->npad / 64));
+    alloc((void **)&h->d_inflag, E * N * 4); alloc((void **)&h->d_sf, E * N * 16);
     if (a == hipSuccess) a = hipMemset(h->d_ng, 0, E * 4);
     if (a == hipSuccess) a = hipMemset(h->d_prior, 0, E * N * 16);
     if (a == hipSuccess && h->d_act_next) a = hipMemset(h->d_act_next, 0, E * N * 16);
@@ -2705,7 +2700,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     if (a == hipSuccess) a = hipMemset(h->d_nei, 0xFF, E * N * (size_t)k.topo * 4);
     if (a == hipSuccess) a = hipMemset(h->d_near, 0, E * N * 4);
     if (a == hipSuccess) a = hipMemset(h->d_inflag, 0, E * N * 4);
-    if (a == hipSuccess) a = hipMemset(h->d_hit, 0, E * N * 8 * (size_t)std::max(1, h->npad / 64));
+    if (a == hipSuccess) a = hipMemset(h->d_sf, 0, E * N * 16);
     if (a == hipSuccess) a = hipMemset(h->d_cells, 0, E * 2 * (size_t)k.ng_max * 8);
     if (a == hipSuccess) a = hipMemset(h->d_cells_xy, 0, E * (size_t)k.ng_max * 16);
     if (a == hipSuccess) a = hipEventCreate(&h->ev0);
@@ -2715,7 +2710,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
         swarm_destroy(h);
         return fail(nullptr, SWARM_ERR_HIP, m);
     }
-    k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag; k.hit = h->d_hit;
+    k.p = h->d_p; k.dp = h->d_dp; k.nei = h->d_nei; k.near_cell = h->d_near; k.in_flag = h->d_inflag; k.sf_next = h->d_sf;
     k.prior_next = h->d_prior; k.act_next = h->d_act_next;
     k.cells = h->d_cells; k.cells_xy = h->d_cells_xy; k.n_g = h->d_ng; k.c_in = h->d_cin;
     k.lat = h->d_lat; k.lattice = 0; k.lat_rw = k.lat_cw = 0; k.lat_nrs = k.lat_nrc = 0; k.lat_n32 = 0;
@@ -2731,7 +2726,7 @@ int swarm_destroy(swarm_env_t *h)
         DeviceGuard g(h->device);
         (void)hipStreamSynchronize(h->stream);
         (void)hipFree(h->d_p); (void)hipFree(h->d_dp); (void)hipFree(h->d_cells); (void)hipFree(h->d_cin); (void)hipFree(h->d_cells_xy);
-        (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag); (void)hipFree(h->d_hit);
+        (void)hipFree(h->d_ng); (void)hipFree(h->d_nei); (void)hipFree(h->d_near); (void)hipFree(h->d_inflag); (void)hipFree(h->d_sf);
         (void)hipFree(h->d_exp_sensed); (void)hipFree(h->d_exp_occ); (void)hipFree(h->d_lat); (void)hipFree(h->d_shape_idx); (void)hipFree(h->d_prior);
         (void)hipFree(h->d_shape_cells); (void)hipFree(h->d_shape_l); (void)hipFree(h->d_shape_cin); (void)hipFree(h->d_shape_ng); (void)hipFree(h->d_shape_lat);
         (void)hipFree(h->d_act_next); (void)hipFree(h->d_io_obs); (void)hipFree(h->d_io_prior); (void)hipFree(h->d_io_rew); (void)hipFree(h->d_io_done);

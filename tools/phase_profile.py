@@ -21,7 +21,8 @@ from marl_llm_amd.synth import synthetic_batch
 
 # stamp ids in program order and what ENDS at each of them
 # (lattice / row-space kernel: the synthetic and the reference's shapes; the generic scan keeps the round-2 stamp points)
-ORDER = [(0, "start"), (1, "prologue loads + barrier"), (2, "forces | prior, integrate, 2 barriers"),
+ORDER = [(0, "start"), (11, "A: state / action / mask loads landed"), (10, "A: forces"), (12, "A: integrate + publish"),
+         (1, "first barrier (others: lattice rows -> LDS, waiting)"), (2, "forces | prior, integrate, 2 barriers"),
          (14, "pair-mask loop"), (15, "pair masks: LDS exchange + barrier"), (3, "ordered insertion (B only)"),
          (16, "lattice walk (not B)"), (17, "barrier after walk"), (4, "nearest merge (LDS)"),
          (5, "kept rows + counts + list fill + barrier"), (18, "rank by list length + barrier"),
