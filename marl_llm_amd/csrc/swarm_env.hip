@@ -280,6 +280,19 @@ __device__ __forceinline__ float psi_u_f32(float u)
 
 // LAT: every env's target cells are a lattice subset (host-detected, KP::lattice) -- a compile-time switch, so that each
 // instantiation carries ONE cell path and stays inside the 64 KB instruction cache.
+// The same weight as a degree-5 polynomial (Chebyshev-node fit; |abs err| < 6.5e-7 in fp32 Horner form): one fused multiply-add
+// less per kept cell in the lattice path's list walk; the reward's guard band there allows 1.2e-6 for it (set_lattice_mode).
+__device__ __forceinline__ float psi5_u_f32(float u)
+{
+    float c = -1.028585434e-02f;
+    c = fmaf(c, u, 1.148182452e-01f);
+    c = fmaf(c, u, -6.661784649e-01f);
+    c = fmaf(c, u, 2.029018402e+00f);
+    c = fmaf(c, u, -2.467372179e+00f);
+    c = fmaf(c, u, 9.999995828e-01f);
+    return c;
+}
+
 template <int NPAD, typename OT, bool DO_STEP, bool LAT>
 __global__ void __launch_bounds__(Geo<NPAD>::T, Geo<NPAD>::WPS)
 k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__restrict__ obs,
@@ -1394,7 +1407,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int ael = NPAD < 64 ? (ea & 63) / NPAD : 0;
         const LatEnv &La = P.lat[(blockIdx.x * EPB + ael) < P.n_env ? (blockIdx.x * EPB + ael) : P.n_env - 1];
         const float Rl = La.R;                                   // d_sen in lattice steps
-        const float inv_r2 = __builtin_amdgcn_rcpf(Rl * Rl);       // 1 ulp: inside the guard band's allowance for psi
+        // the walk works in units of d_sen (coordinates scaled by 1 / R): u = da^2 + db^2 needs no further factor, and the
+        // |v| threshold becomes the constant 0.05 / d_sen.  (1 / R to 1 ulp: inside the guard band's allowance for psi)
+        const float inv_r = __builtin_amdgcn_rcpf(Rl);
+        const float apr_s = apr * inv_r;
         const u64 *rma = lrm + ael * 64;
         const uint4 cq = reinterpret_cast<const uint4 *>(pcr)[ea];
         const int s0 = (int)__builtin_amdgcn_sad_u8(cq.x, 0u, 0u), s1 = (int)__builtin_amdgcn_sad_u8(cq.y, 0u, 0u);
@@ -1434,7 +1450,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int bt0 = ab0 + t;
         const u64 *rmp = rma + (bt0 < 0 ? 0 : (bt0 > 63 ? 63 : bt0));
         unsigned relm = (unsigned)(*rmp >> aca0);
-        float dbf = (float)t - bpr, db2 = dbf * dbf;
+        float dbf = ((float)t - bpr) * inv_r, db2 = dbf * dbf;
         float n0 = 0.0f, n1 = 0.0f, dn = 0.0f;
         short *row = sidx + (size_t)ea * P.g_stride;
         const unsigned nm1 = (unsigned)(nk - 1);
@@ -1468,7 +1484,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         const unsigned wd = *srp;
                         kept = wd & 0x1FFFFu; base = (int)(wd >> 17);
                         relm = (unsigned)(*rmp >> aca0);
-                        dbf += 1.0f; db2 = dbf * dbf;
+                        dbf += inv_r; db2 = dbf * dbf;
                     }
                     if (kept != 0) {
                         const int c = __ffs(kept) - 1;
@@ -1484,9 +1500,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                         if constexpr (CAP) { if (take) row[slot] = (short)cell; slot += take ? 1 : 0; }
                         else row[k] = (short)cell;                   // under the cap the slot of a cell is its rank
                         ++k;
-                        const float da = (float)c - apr;
-                        const float u = fmaf(da, da, db2) * inv_r2;
-                        float psi = psi_u_f32(u);
+                        const float da = fmaf((float)c, inv_r, -apr_s);
+                        const float u = fmaf(da, da, db2);
+                        float psi = psi5_u_f32(u);
                         if constexpr (CAP) psi = take ? psi : 0.0f;
                         n0 = fmaf(psi, da, n0); n1 = fmaf(psi, dbf, n1); dn += psi;
                     }
@@ -1517,11 +1533,13 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int ae = blockIdx.x * EPB + ael;
         const bool lead = (lane & 3) == 0 && ae < P.n_env && ai < n_a;
         const bool has = lead && in_a && nsl > 0;
-        const float thr = P.rew_thr_k * qrl;                         // 0.05 in lattice steps
-        const float v0f = qn0 / qdn, v1f = qn1 / qdn;
+        const float thr = P.rew_thr_k;                               // 0.05 in units of d_sen (the walk's scale)
+        const float idn = __builtin_amdgcn_rcpf(qdn);                // (1 ulp + two roundings: far inside the 4e-6 the band allows)
+        const float v0f = qn0 * idn, v1f = qn1 * idn;
         const float vf = sqrtf(fmaf(v0f, v0f, v1f * v1f));
         bool uni = has && vf < thr;
-        const bool uns = has && (P.force_exact || !(qdn > 1e-6f) || !(fabsf(vf - thr) > P.rew_ga_lat * (float)nsl / qdn + P.rew_gb_lat));
+        const float inv_rl = __builtin_amdgcn_rcpf(qrl);             // the band is kept in lattice steps on the host: scale it
+        const bool uns = has && (P.force_exact || !(qdn > 1e-6f) || !(fabsf(vf - thr) > (P.rew_ga_lat * (float)nsl * idn + P.rew_gb_lat) * inv_rl * 1.0001f));
         u64 um = __ballot(uns);
         while (um != 0) {
             const int L = __ffsll((unsigned long long)um) - 1;
@@ -2477,11 +2495,12 @@ void set_lattice_mode(swarm_env *h, bool all_lattice, float rmax, float cmax, in
     k.lattice = (all_lattice && !h->lattice_disabled && k.lat_nrs <= 15) ? 1 : 0;
     {   // guard band of the fp32 reward decision of the lattice path, in lattice steps (R = d_sen / l <= rmax).  Per cell the
         // model coordinate relative to the agent is off by dx: lattice fit tolerance 1.5e-6 steps, fp32 cast of the relative
-        // coordinate (|.| <= 17 steps) and its subtraction 2.1e-6, margin: 6e-6.  As in swarm_create: psi is off by
-        // dpsi <= (pi^2 / 4) (2 sqrt(2) dx / R) + 4e-7, |v| by n (dpsi R + dx + thr dpsi) / den, thr = 0.05 R / d_sen;
+        // coordinate (|.| <= 17 steps) 2.1e-6, the walk's scaled form c / R - a / R (two products of magnitude <= 17 / R with
+        // a 1-ulp reciprocal, cancelling) 5e-6, margin: 1.2e-5.  As in swarm_create: psi is off by
+        // dpsi <= (pi^2 / 4) (2 sqrt(2) dx / R) + 1.2e-6, |v| by n (dpsi R + dx + thr dpsi) / den, thr = 0.05 R / d_sen;
         // fp32 accumulation / division / sqrt: 4e-6 relative to d_sen, i.e. 4e-6 R / d_sen steps.  1.3x margin.
-        const double dx = 6e-6, R = std::fmax(1.0, (double)rmax), thr = 0.05 * R / k.d_sen;
-        const double dpsi_R = 2.4675 * 2.0 * std::sqrt(2.0) * dx + 8e-7 * R;        // dpsi * R (8e-7: polynomial 4e-7 + the 1-ulp reciprocal of R^2)
+        const double dx = 1.2e-5, R = std::fmax(1.0, (double)rmax), thr = 0.05 * R / k.d_sen;
+        const double dpsi_R = 2.4675 * 2.0 * std::sqrt(2.0) * dx + 1.2e-6 * R;      // dpsi * R (1.2e-6: degree-5 polynomial 6.5e-7 + the 1-ulp reciprocal scaling)
         k.rew_ga_lat = (float)(1.3 * (dpsi_R + dx + thr * dpsi_R / R));
         k.rew_gb_lat = (float)(4e-6 * R / k.d_sen);
     }
