@@ -222,9 +222,17 @@ __device__ __forceinline__ double clamp_ref(double v, double lo, double hi)
 // per-agent sequential work (forces / integration / reward decision; prior / ordered neighbour insertion); rows,
 // words, slots and rank ranges of the other phases are dealt over all splits.  One environment's LDS footprint is
 // thereby shared by four times more wavefronts, which is what buys the occupancy that hides the LDS / fp64 latencies.
-template <int NPAD> struct Geo {
+// HALF (N < 64, lattice launches, small grids): only half of the 64 agent threads hold agents -- half as many environments
+// per workgroup, twice as many workgroups -- and the list phase gives every agent EIGHT lanes instead of four.  A batch that
+// fills a fraction of the chip (32 agents x 1024 envs: 512 workgroups on 256 CUs) is bound by the length of one workgroup's
+// serial chain, not by throughput: shorter chains on more workgroups.
+template <int NPAD, bool HALF = false> struct Geo {
+    static_assert(!HALF || NPAD < 64, "the half-occupied geometry is for N < 64");
     static constexpr int AG = NPAD < 64 ? 64 : NPAD;
-    static constexpr int EPB = NPAD < 64 ? 64 / NPAD : 1;
+    static constexpr int EPB = NPAD < 64 ? (64 / NPAD) / (HALF ? 2 : 1) : 1;
+    static constexpr int ACTW = NPAD < 64 ? EPB * NPAD : 64;     // agent threads of a 64-group that hold agents
+    static constexpr int LPA = HALF ? 8 : 4;                     // lanes per agent in the list phase
+    static constexpr int AGW = 64 / LPA;                         // agents per wave there (= ACTW / 4)
     static constexpr int NW = AG / 64;
     static constexpr int WPE = 4;
     static constexpr int T = AG * WPE;
@@ -293,12 +301,15 @@ __device__ __forceinline__ float psi5_u_f32(float u)
     return c;
 }
 
-template <int NPAD, typename OT, bool DO_STEP, bool LAT>
-__global__ void __launch_bounds__(Geo<NPAD>::T, Geo<NPAD>::WPS)
+template <int NPAD, typename OT, bool DO_STEP, bool LAT, bool HALF = false>
+__global__ void __launch_bounds__((Geo<NPAD, HALF>::T), (Geo<NPAD, HALF>::WPS))
 k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__restrict__ obs,
       float *__restrict__ reward, uint8_t *__restrict__ done, OT *__restrict__ a_prior)
 {
-    constexpr int AG = Geo<NPAD>::AG, EPB = Geo<NPAD>::EPB, NW = Geo<NPAD>::NW, WPE = Geo<NPAD>::WPE, T = Geo<NPAD>::T;
+    typedef Geo<NPAD, HALF> G_;
+    constexpr int AG = G_::AG, EPB = G_::EPB, NW = G_::NW, WPE = G_::WPE, T = G_::T;
+    constexpr int ACTW = G_::ACTW, LPA = G_::LPA, AGW = G_::AGW;
+    static_assert(!HALF || LAT, "the half-occupied geometry exists for the lattice path only");
     typedef typename Pair<OT>::type OT2;
 
     extern __shared__ __align__(16) unsigned char smem[];
@@ -338,11 +349,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // ordered insertion, reward combine) -- rotating spreads that over the four SIMDs of a CU.
     const int sx = __builtin_amdgcn_readfirstlane((tid / AG + (int)blockIdx.x) % WPE);
     const int aw = at >> 6;                  // which 64-agent group of the environment
-    const int el = NPAD < 64 ? at / NPAD : 0;
+    const bool thr_on = NPAD >= 64 || at < ACTW;         // (half-occupied geometry: agent threads ACTW..63 hold nothing)
+    const int el = (NPAD < 64 && thr_on) ? at / NPAD : 0;
     const int i = NPAD < 64 ? at % NPAD : at;
     const int e = blockIdx.x * EPB + el;
     const int n_a = P.n_a;
-    const bool act = (e < P.n_env) && (i < n_a);
+    const bool act = thr_on && (e < P.n_env) && (i < n_a);
     const int es = e < P.n_env ? e : P.n_env - 1;
     const int ng = P.n_g[es];
     int ngb = ng;
@@ -1231,7 +1243,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             // row slot k of this wave -> agent thread tr, environment in the workgroup elr, output row r, "row exists"
             auto locate = [&](int k, int &tr, int &elr, int &r) -> bool {
                 if (own) {
-                    const int ta = (at & ~63) + pw[sx * 16 + k];
+                    const int ta = (at & ~63) + pw[(64 - ACTW) + sx * AGW + k];
                     const int ii = NPAD < 64 ? (ta & 63) % NPAD : ta;
                     elr = NPAD < 64 ? (ta & 63) / NPAD : 0;
                     tr = ta; r = elr * n_a + ii;
@@ -1249,7 +1261,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 // consecutive addresses -- half the store instructions of the pair-per-lane form.  A row has 40 two-slot
                 // chunks; 8 rows = 320 chunks = 5 full passes.
                 typedef OT OT4 __attribute__((ext_vector_type(4)));
-                const int ngrp = own ? 2 : (rows + nwv * 8 - 1) / (nwv * 8);
+                const int ngrp = own ? AGW / 8 : (rows + nwv * 8 - 1) / (nwv * 8);
                 for (int g8 = 0; g8 < ngrp; ++g8) {
 #pragma unroll
                     for (int ps = 0; ps < 5; ++ps) {
@@ -1274,7 +1286,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 }
             } else {
                 // any other list length / f64 rows: wave per row, lane = slot
-                const int nrow = own ? 16 : (rows - wv + nwv - 1) / nwv;
+                const int nrow = own ? AGW : (rows - wv + nwv - 1) / nwv;
                 for (int k = 0; k < nrow; ++k) {
                     int tr, elr, r;
                     const bool ok = locate(own ? k : wv + k * nwv, tr, elr, r);
@@ -1368,7 +1380,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     {
         const uint4 cq = reinterpret_cast<const uint4 *>(pcr)[at];
         n_kept = (int)__builtin_amdgcn_sad_u8(cq.x, 0u, __builtin_amdgcn_sad_u8(cq.y, 0u, __builtin_amdgcn_sad_u8(cq.z, 0u, __builtin_amdgcn_sad_u8(cq.w, 0u, 0u))));
-        const int key = n_kept * 64 + lane;
+        const int key = (lane < ACTW) ? n_kept * 64 + lane : lane - 64;      // empty agent threads first, in lane order
         int cnt = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) cnt += (__builtin_amdgcn_readlane(key, sx * 16 + q) < key) ? 1 : 0;
@@ -1388,7 +1400,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        ea = (at & ~63) + pw[sx * 16 + (lane >> 2)];     // split 0 takes the sixteen shortest lists, split 3 the longest
+        // LPA lanes per agent, AGW agents per wave: split 0 takes the shortest lists, split 3 the longest
+        ea = (at & ~63) + pw[(64 - ACTW) + sx * AGW + lane / LPA];
     }
 
     // ---- (E) capped sensed list (CPP:236-271) + exploration-reward sums (CPP:494-551), fp32 fast path.  The kept list of
@@ -1400,7 +1413,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     float qn0 = 0.0f, qn1 = 0.0f, qdn = 0.0f, qrl = 1.0f; int qnk = 0;      // the quad's reward sums / list length / d_sen in steps
     for (int rep = 0, reps = REPS(11); rep < reps; ++rep) {
         FENCE();
-        const int sub = lane & 3;
+        const int sub = lane & (LPA - 1);
         const float4 ha = hdr[ea];
         const float apr = ha.x, bpr = ha.y;
         const int ab0 = __float_as_int(ha.z), aca0 = __float_as_int(ha.w);
@@ -1416,7 +1429,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const int s0 = (int)__builtin_amdgcn_sad_u8(cq.x, 0u, 0u), s1 = (int)__builtin_amdgcn_sad_u8(cq.y, 0u, 0u);
         const int s2 = (int)__builtin_amdgcn_sad_u8(cq.z, 0u, 0u), s3 = (int)__builtin_amdgcn_sad_u8(cq.w, 0u, 0u);
         const int nk = s0 + s1 + s2 + s3;
-        const int per = (nk + 3) >> 2;
+        const int per = (nk + LPA - 1) / LPA;
         const int k0 = sub * per < nk ? sub * per : nk;
         const int k1 = k0 + per < nk ? k0 + per : nk;
         // the window row holding rank k0: the LAST row whose first rank is <= k0 (empty rows in front of it are skipped)
@@ -1516,7 +1529,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
             return v;
         };
-        qn0 = quad_sum(n0); qn1 = quad_sum(n1); qdn = quad_sum(dn); qnk = nk; qrl = Rl;
+        auto lanes_sum = [&](float v) -> float {                     // ... and the second quad's sum into an 8-lane group's first lane
+            v = quad_sum(v);
+            if constexpr (LPA == 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xF, 0xF, true));   // row_shl:4
+            return v;
+        };
+        qn0 = lanes_sum(n0); qn1 = lanes_sum(n1); qdn = lanes_sum(dn); qnk = nk; qrl = Rl;
     }
     STAMP(19);
     EXIT_AT(9);
@@ -1531,7 +1549,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         const bool in_a = (sncf[ea] >> 30) != 0;
         const int ael = NPAD < 64 ? (ea & 63) / NPAD : 0, ai = NPAD < 64 ? (ea & 63) % NPAD : ea;
         const int ae = blockIdx.x * EPB + ael;
-        const bool lead = (lane & 3) == 0 && ae < P.n_env && ai < n_a;
+        const bool lead = (lane & (LPA - 1)) == 0 && ae < P.n_env && ai < n_a;
         const bool has = lead && in_a && nsl > 0;
         const float thr = P.rew_thr_k;                               // 0.05 in units of d_sen (the walk's scale)
         const float idn = __builtin_amdgcn_rcpf(qdn);                // (1 ulp + two roundings: far inside the 4e-6 the band allows)
@@ -2281,7 +2299,9 @@ struct swarm_env {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool have_cells, have_state, observed;
-    int attr_smem[12];
+    int attr_smem[24];
+    bool half;                     // the half-occupied geometry is in use (set_lattice_mode)
+    int n_cu;
     std::vector<char> cells_set;
     std::string err;
     // device buffers
@@ -2411,10 +2431,11 @@ bool detect_lattice(const double *gx, const double *gy, int n, LatEnv &L)
     return true;
 }
 
-template <int NPAD>
+template <int NPAD, bool HALF>
 void layout_t(KP &k)
 {
-    constexpr int AG = Geo<NPAD>::AG, EPB = Geo<NPAD>::EPB, NW = Geo<NPAD>::NW, WPE = Geo<NPAD>::WPE, T = Geo<NPAD>::T;
+    typedef Geo<NPAD, HALF> G_;
+    constexpr int AG = G_::AG, EPB = G_::EPB, NW = G_::NW, WPE = G_::WPE, T = G_::T;
     k.ngw = (k.ng_max + 31) / 32;
     k.cxy_stride = k.ngw * 32 + 1;            // +1 pair: envs of one wave start on different LDS banks
     int half = (k.g_max + 1) / 2;
@@ -2469,15 +2490,15 @@ void layout_t(KP &k)
     k.off_hdr = k.off_srow = k.off_pcr = k.off_perm = k.off_rres = k.off_orow = k.off_partd = 0;
 }
 
-void layout(KP &k, int npad)
+void layout(KP &k, int npad, bool half)
 {
     switch (npad) {
-    case 8: layout_t<8>(k); break;
-    case 16: layout_t<16>(k); break;
-    case 32: layout_t<32>(k); break;
-    case 64: layout_t<64>(k); break;
-    case 128: layout_t<128>(k); break;
-    default: layout_t<256>(k); break;
+    case 8: if (half) layout_t<8, true>(k); else layout_t<8, false>(k); break;
+    case 16: if (half) layout_t<16, true>(k); else layout_t<16, false>(k); break;
+    case 32: if (half) layout_t<32, true>(k); else layout_t<32, false>(k); break;
+    case 64: layout_t<64, false>(k); break;
+    case 128: layout_t<128, false>(k); break;
+    default: layout_t<256, false>(k); break;
     }
 }
 
@@ -2504,19 +2525,26 @@ void set_lattice_mode(swarm_env *h, bool all_lattice, float rmax, float cmax, in
         k.rew_ga_lat = (float)(1.3 * (dpsi_R + dx + thr * dpsi_R / R));
         k.rew_gb_lat = (float)(4e-6 * R / k.d_sen);
     }
-    layout(k, h->npad);
+    // a small batch of small environments (N < 64) that leaves at least half of the chip's workgroup slots empty: the
+    // half-occupied geometry (Geo<NPAD, true>) -- twice the workgroups, eight lanes per agent in the list phase
+    {
+        const int epb_full = h->npad < 64 ? 64 / h->npad : 1;
+        const long long grid_full = ((long long)h->cfg.n_env + epb_full - 1) / epb_full;
+        h->half = k.lattice && h->npad < 64 && epb_full >= 2 && !(h->cfg.debug_flags & 4) && 2 * grid_full <= (long long)h->n_cu * 5;
+    }
+    layout(k, h->npad, h->half);
 }
 
-template <int NPAD, typename OT, bool DO_STEP, bool LAT>
+template <int NPAD, typename OT, bool DO_STEP, bool LAT, bool HALF>
 int launch_t(swarm_env *h, const void *action, int act_f64, void *obs, float *reward, uint8_t *done, void *a_prior)
 {
-    constexpr int T = Geo<NPAD>::T, EPB = Geo<NPAD>::EPB;
-    auto kern = k_env<NPAD, OT, DO_STEP, LAT>;
+    constexpr int T = Geo<NPAD, HALF>::T, EPB = Geo<NPAD, HALF>::EPB;
+    auto kern = k_env<NPAD, OT, DO_STEP, LAT, HALF>;
     int smem = !LAT ? h->kp.smem_generic : (h->kp.export_idx ? h->kp.smem_lat_export : h->kp.smem_lat);
 #ifdef SWARM_EXTRA_SMEM
     smem += SWARM_EXTRA_SMEM;                            // occupancy experiments only
 #endif
-    int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : sizeof(OT) == 2 ? 4 : 0) + (LAT ? 6 : 0)];   // raise the dynamic-LDS cap once per instantiation
+    int &attr = h->attr_smem[(DO_STEP ? 1 : 0) + (sizeof(OT) == 8 ? 2 : sizeof(OT) == 2 ? 4 : 0) + (LAT ? 6 : 0) + (HALF ? 12 : 0)];   // raise the dynamic-LDS cap once per instantiation
     if (attr < smem) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = smem;
@@ -2531,8 +2559,11 @@ int launch_t(swarm_env *h, const void *action, int act_f64, void *obs, float *re
 template <int NPAD, typename OT, bool DO_STEP>
 int launch_l(swarm_env *h, const void *action, int act_f64, void *obs, float *reward, uint8_t *done, void *a_prior)
 {
-    return h->kp.lattice ? launch_t<NPAD, OT, DO_STEP, true>(h, action, act_f64, obs, reward, done, a_prior)
-                         : launch_t<NPAD, OT, DO_STEP, false>(h, action, act_f64, obs, reward, done, a_prior);
+    if constexpr (NPAD < 64) {
+        if (h->kp.lattice && h->half) return launch_t<NPAD, OT, DO_STEP, true, true>(h, action, act_f64, obs, reward, done, a_prior);
+    }
+    return h->kp.lattice ? launch_t<NPAD, OT, DO_STEP, true, false>(h, action, act_f64, obs, reward, done, a_prior)
+                         : launch_t<NPAD, OT, DO_STEP, false, false>(h, action, act_f64, obs, reward, done, a_prior);
 }
 
 template <int NPAD>
@@ -2614,6 +2645,7 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
     h->cfg = *cfg; h->device = dev; h->stream = nullptr; h->ev0 = h->ev1 = nullptr;
     h->have_cells = h->have_state = h->observed = false;
     for (int &a : h->attr_smem) a = -1;
+    h->half = false; h->n_cu = 256;
     h->d_p = h->d_dp = h->d_cells = h->d_cin = nullptr; h->d_cells_xy = nullptr;
     h->d_lat = nullptr;
     h->n_shapes = 0; h->d_shape_cells = h->d_shape_l = h->d_shape_cin = nullptr; h->d_shape_ng = nullptr; h->d_shape_lat = nullptr; h->d_shape_idx = nullptr;
@@ -2690,12 +2722,13 @@ int swarm_create(const swarm_config_t *cfg, swarm_env_t **out)
         k.dbg_phase = (cfg->debug_flags >> 8) & 0xF;
         k.dbg_extra = (cfg->debug_flags >> 12) & 0xF;
     }
-    layout(k, h->npad);
+    layout(k, h->npad, false);
 
     DeviceGuard g(dev);
     if (!g.ok) { delete h; return fail(nullptr, SWARM_ERR_HIP, "hipSetDevice failed"); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return fail(nullptr, SWARM_ERR_HIP, "hipGetDeviceProperties failed"); }
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((size_t)k.smem_generic > 160 * 1024) {
         delete h;
         return fail(nullptr, SWARM_ERR_INVALID, "configuration needs more LDS per workgroup than the device has (reduce n_cells_max / num_obs_grid_max)");
@@ -3180,7 +3213,7 @@ int swarm_debug_stamps(swarm_env_t *h, const void *action, int action_dtype, voi
 {
     if (!h || !out) return -1;
     DeviceGuard g(h->device);
-    const int epb = h->npad < 64 ? 64 / h->npad : 1;
+    const int epb = h->npad < 64 ? (64 / h->npad) / (h->half ? 2 : 1) : 1;
     const int grid = (h->cfg.n_env + epb - 1) / epb;   // same for every Geo<NPAD>
     const int wpb = (h->npad < 64 ? 64 : h->npad) * 4 / 64;      // waves per workgroup
     if (grid > max_blocks) return -1;

@@ -557,3 +557,45 @@ def test_near_ties_whose_norms_coincide(oracle, shapes):
         assert np.array_equal(obs[e], _to_rows(o["obs"])), e
     assert collapsed == E
     sb.close()
+
+
+@pytest.mark.parametrize("n_a,n_env,periodic", [(8, 37, False), (16, 9, True), (30, 21, False), (32, 64, False), (32, 5, True)])
+def test_half_occupied_geometry_equals_the_full_one(oracle, shapes, n_a, n_env, periodic):
+    """Small batches of N < 64 agents run with half of the agent threads empty and eight lanes per agent in the list phase
+    (twice the workgroups: Geo<NPAD, true>); debug_flags bit 2 keeps the full geometry.  Both must give the same bits as
+    each other on free-running steps, and the oracle's on the last one."""
+    from marl_llm_amd.shapes import r_avoid_for
+    from marl_llm_amd.synth import synthetic_batch
+    ra = r_avoid_for(n_a, shapes)
+    sy = synthetic_batch(n_env, n_a, shapes, seed=17 + n_a, assembled_fraction=0.7)
+    outs = []
+    for flags in (0, 4):
+        sb = _batch(n_env=n_env, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=ra, is_boundary=not periodic,
+                    obs_dtype=torch.float64, debug_flags=flags)
+        sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"]); sb.set_state(sy["p"], sy["dp"]); sb.observe()
+        act = torch.zeros((n_env, n_a, 2), dtype=torch.float64, device=sb.device)
+        rews = []
+        for t in range(12):
+            if t == 11:
+                p0, dp0 = [x.cpu().numpy() for x in sb.get_state()]
+                nei0 = sb.indices(False, False)["neighbor_index"].cpu().numpy()
+                a0 = act.cpu().numpy()
+            obs, rew, done, pri = sb.step(act)
+            act = pri.clone()
+            rews.append(rew.clone())
+        idx = sb.indices()
+        p, dp = sb.get_state()
+        outs.append((obs.clone(), torch.stack(rews), pri.clone(), p, dp, idx["sensed_index"], idx["occupied_index"],
+                     idx["neighbor_index"], idx["in_flags"], p0, dp0, nei0, a0))
+        sb.close()
+    for a, b in zip(outs[0][:9], outs[1][:9]):
+        assert torch.equal(a, b)
+    obs, rews, pri, p, dp, sen, occ, nei, inf, p0, dp0, nei0, a0 = outs[0]
+    for e in range(min(n_env, 6)):
+        g = sy["cells"][e][:, : sy["n_g"][e]]
+        s = oracle.step(p0[e], dp0[e], np.ascontiguousarray(a0[e].T), g, nei0[e], float(sy["l_cell"][e]), ra, is_boundary=not periodic)
+        assert np.array_equal(p[e].cpu().numpy(), s["p"]) and np.array_equal(dp[e].cpu().numpy(), s["dp"])
+        assert np.array_equal(obs[e].cpu().numpy(), _to_rows(s["obs"]))
+        assert np.array_equal(rews[-1][e].cpu().numpy().astype(np.float64), s["reward"][0])
+        assert np.array_equal(pri[e].cpu().numpy(), _to_rows(s["a_prior"]))
+        assert np.array_equal(sen[e].cpu().numpy(), s["sensed_index"]) and np.array_equal(occ[e].cpu().numpy(), s["occupied_index"])

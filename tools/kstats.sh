@@ -6,7 +6,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 T=$(mktemp -d)
 cd $T && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$R/include --save-temps -c $R/marl_llm_amd/csrc/swarm_env.hip -o $T/o.o 2>/dev/null
 S=$T/swarm_env-hip-amdgcn-amd-amdhsa-gfx950.s
-for K in "ILi64EfLb1ELb1E" "ILi64EfLb1ELb0E" "ILi64EfLb0ELb1E" "ILi32EfLb1ELb1E" "ILi8EfLb1ELb1E" "ILi128EfLb1ELb1E" "ILi256EfLb1ELb1E" "ILi256EfLb1ELb0E" "ILi64EdLb1ELb1E"; do
+for K in "ILi64EfLb1ELb1ELb0E" "ILi64EfLb1ELb0ELb0E" "ILi64EfLb0ELb1ELb0E" "ILi32EfLb1ELb1ELb0E" "ILi32EfLb1ELb1ELb1E" "ILi8EfLb1ELb1ELb0E" "ILi128EfLb1ELb1ELb0E" "ILi256EfLb1ELb1ELb0E" "ILi256EfLb1ELb0ELb0E" "ILi64EdLb1ELb1ELb0E"; do
   L=$(grep -n "^_ZN12_GLOBAL__N_15k_env${K}EEvNS_2KPEPKviPT0_PfPhS5_:" $S | cut -d: -f1)
   E=$(awk -v L=$L 'NR>L && /\.end_amdhsa_kernel/{print NR; exit}' $S)
   echo "k_env<$K>" $(awk -v L=$L 'NR>L && /; (NumVgprs|ScratchSize|Occupancy|codeLenInByte)/{printf "%s ", $0; n++} n>=4{exit}' $S) "; spill instructions:" $(sed -n "${L},${E}p" $S | grep -c "Folded Spill\|Folded Reload")
