@@ -435,9 +435,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
     }
     if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
-    if constexpr (NW > 1) {                       // pair-mask accumulators (OR-ed into with LDS atomics)
-        for (int k = sx; k < 5 * NW; k += WPE) pm[k * AG + at] = 0;
-    }
     if (sx == 0) sflag[at] = 0;
     if constexpr (use_lat) {
         for (int q = tid; q < EPB * 64; q += T) {
@@ -537,9 +534,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // every split evaluates 1/WPE of the agents j of each 64-agent group (branch-free, unrolled); the partial masks
     // are OR-combined through LDS so that every lane ends up with its complete "nearby" masks (split B also with the
     // candidate masks)
-    u64 nearbyN[NW], candN[NW], cand1N[NW], cand2N[NW], hitN[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) hitN[w] = 0;
+    u64 nearbyN[NW], candN[NW], cand1N[NW], cand2N[NW], hitN[NW] = {};
     {
         constexpr int JQ = JN / WPE;                  // agents j per split and 64-agent group
         static_assert(JQ * WPE == JN && JQ <= 32, "pair pass: JN must split evenly into <= 32 agents per split");
@@ -571,22 +566,26 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     if constexpr (NW > 2) c2 = shl1_or_mask(c2, __ballot(d2 < P.c_close2));           // wider pre-selection ring (N > 128: pays there)
                 }
                 exc = exc || (a_hi != nb);             // some agent is not "nearby" by a hair (see the occupied-cell filter)
-                if constexpr (NW == 1) { a_nb[0] = nb; a_cd[0] = cd; a_c1[0] = c1; a_ht[0] = ht; }
+                if constexpr (NPAD < 64) { a_nb[0] = nb; a_cd[0] = cd; a_c1[0] = c1; a_ht[0] = ht; }
                 else if (rep == reps - 1) {
-                    // N > 64: per-split copies of the masks would not fit beside the rest; the splits OR their parts into ONE
-                    // set of accumulators (zeroed in the prologue) with LDS atomics
-                    atomicOr(&pm[(0 * NW + w) * AG + at], place(nb));
-                    atomicOr(&pm[(1 * NW + w) * AG + at], place(cd));
-                    atomicOr(&pm[(2 * NW + w) * AG + at], place(c1));
-                    atomicOr(&pm[(3 * NW + w) * AG + at], place(ht));
-                    atomicOr(&pm[(4 * NW + w) * AG + at], place(c2));
+                    // N >= 64: a split's share of a 64-agent group is JQ = 16 agents -- exactly one 16-bit quarter of the
+                    // group's mask word.  Each split stores its quarter (plain 2-byte store, no atomics, nothing to zero);
+                    // behind the barrier a reader gets the whole 64-bit word with one load.
+                    unsigned short *pq = reinterpret_cast<unsigned short *>(pm) + sx;
+                    auto quarter = [](unsigned acc) -> unsigned short { return (unsigned short)(__brev(acc) >> 16); };
+                    pq[((size_t)(0 * NW + w) * AG + at) * 4] = quarter(nb);
+                    pq[((size_t)(1 * NW + w) * AG + at) * 4] = quarter(cd);
+                    pq[((size_t)(2 * NW + w) * AG + at) * 4] = quarter(c1);
+                    pq[((size_t)(3 * NW + w) * AG + at) * 4] = quarter(ht);
+                    if constexpr (NW > 2) pq[((size_t)(4 * NW + w) * AG + at) * 4] = quarter(c2);
                 }
             }
         }
         STAMP(14);
         if (use_lat && exc) atomicOr(&sflag[at], 1);   // resolve the occupied-cell filter of this agent exactly
-        if constexpr (NW == 1) {
-            // N <= 64: every split stores its partial masks, the readers OR the WPE copies
+        if constexpr (NPAD < 64) {
+            // N < 64 (several environments per wavefront, JQ < 16): every split stores its partial masks, the readers OR the
+            // WPE copies
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 // bit position of agent j in the wave-wide masks = its lane (el*NPAD + j)
