@@ -550,7 +550,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             exc = false;
             // (N > 64: the loop over the 64-agent groups stays rolled -- unrolled, the pair pass alone was 20 KB of a kernel
             // that has to fit a 64 KB instruction cache)
-#pragma unroll (NW == 1 ? 2 : 1)
+#pragma unroll 1
             for (int w = 0; w < NW; ++w) {
                 unsigned nb = 0, cd = 0, c1 = 0, ht = 0, c2 = 0, a_hi = 0;
                 const double *qx = spx + w * 64 + sx * JQ, *qy = spy + w * 64 + sx * JQ;
