@@ -17,9 +17,12 @@ NAMES = ["forces+prior+integrate", "pair masks", "cell scan", "occupied filter",
          "obs head pairs", "obs sensed pairs", "cell staging", "ordered insertion", "emit walk", "nearest merge"]
 
 
-SEGS = [(0, "loads+first barrier"), (1, "forces+integrate"), (2, "pair masks"), (3, "ordered insertion"), (4, "cell walk"),
-        (5, "nearest merge"), (6, "kept rows + counts"), (7, "rank by list length"), (9, "emit + reward sums"),
-        (10, "reward combine"), (11, "obs head pairs"), (None, "obs sensed pairs (full kernel)")]
+# (exit code, label) in program order of the lattice (row-space) kernel; the early exits' TIMES below ~10 us are bounded by the
+# host's launch rate, their instruction counts are exact
+SEGS = [(0, "loads + integration + first barrier"), (1, "(state re-read)"), (2, "pair masks"),
+        (3, "contact spring + ordered insertion (B)"), (4, "cell walk"), (5, "nearest merge"), (6, "kept rows + counts"),
+        (7, "rank by list length"), (9, "list emission + reward sums"), (10, "reward verdict (in-wave)"),
+        (11, "prior (B) | obs heads (A, C)"), (None, "obs rows of the waves' own agents (full kernel)")]
 
 
 def run(skip, n_a, E, sy, ra, state, steps=int(os.environ.get('ABLATE_STEPS', '60'))):
