@@ -355,7 +355,7 @@ def latency_worker_main():
 def extra_configs(torch, args, device):
     """other_configs beyond the kernel shapes: the numpy drop-in API (the path the unchanged trainer drives,
     train_assembly.py:97-111) at the reference's default scale and at the headline batch, the legacy shim, the device
-    rollout."""
+    rollout.  Every part reports its own failure instead of taking the bench line down."""
     from marl_llm_amd.env import AssemblySwarmEnv, make_args
     from marl_llm_amd.shapes import synthetic_shape_set
     res = []
@@ -371,38 +371,41 @@ def extra_configs(torch, args, device):
     # (2) numpy API, 1 env x 30 agents (assembly_cfg.py:153 default): obs / reward / prior come back as the reference's
     #     float64 host arrays every step
     for n_envs, n_a, steps in ((1, 30, 300), (4096, 64, 12)):
-        env = AssemblySwarmEnv(n_envs=n_envs, device=device, obs_dtype="float64", rng="counter", seed=args.seed, host_copy=False)
-        env.__reinit__(make_args(n_a=n_a, results_file=shapes))
-        env.reset()
-        a = np.zeros((2, n_envs * n_a), np.float32)
-        for _ in range(5 if n_envs > 1 else 50):                       # assemble a little, warm up
-            a = env.step(a)[4].astype(np.float32)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            a = env.step(a)[4].astype(np.float32)                      # the trainer's loop shape: host action from host outputs
-        total_ms = (time.perf_counter() - t0) / steps * 1e3
-        b = env._backend()
-        act = torch.zeros((n_envs, n_a, 2), device=b.device)
-        b.timer_start()
-        for _ in range(steps):
-            b.step(act)
-        dev_ms = b.timer_stop() / steps
-        rec = {"workload": f"numpy drop-in API (AssemblySwarmEnv.step), {n_a} agents x {n_envs} env(s), float64 host arrays in the reference's layouts",
-               "ms_per_step": total_ms, "agent_steps_per_s": n_envs * n_a / (total_ms * 1e-3),
-               "device_step_kernel_ms": dev_ms,
-               "host_boundary_ms": total_ms - dev_ms,
-               "what": "one C call per step: pinned action staging -> H2D -> k_env (f64 rows) -> k_export (widen + transpose on the "
-                       "device) -> ONE D2H into a pinned slot -> sync; host_boundary_ms = everything but the step kernel "
-                       "(incl. the caller's astype of the next action)"}
-        if n_envs == 1:
-            rec["reference_cpu_ms_per_step"] = lat.get("reference_cpu_n30_ms_per_step")
-        else:
-            blk = b.obs_dim * n_envs * n_a * 8 + 3 * n_envs * n_a * 8 + n_envs * n_a
-            rec["host_block_bytes"] = blk
-            rec["d2h_GBps_if_all_boundary_time_were_the_copy"] = blk / ((total_ms - dev_ms) * 1e-3) / 1e9
-        res.append(rec)
-        env.close()
-        del env
+        label = (f"numpy drop-in API (AssemblySwarmEnv.step), {n_a} agents x {n_envs} env(s), float64 host arrays in the "
+                 "reference's layouts")
+        try:
+            env = AssemblySwarmEnv(n_envs=n_envs, device=device, obs_dtype="float64", rng="counter", seed=args.seed, host_copy=False)
+            env.__reinit__(make_args(n_a=n_a, results_file=shapes))
+            env.reset()
+            a = np.zeros((2, n_envs * n_a), np.float32)
+            for _ in range(5 if n_envs > 1 else 50):                   # assemble a little, warm up
+                a = env.step(a)[4].astype(np.float32)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                a = env.step(a)[4].astype(np.float32)                  # the trainer's loop shape: host action from host outputs
+            total_ms = (time.perf_counter() - t0) / steps * 1e3
+            b = env._backend()
+            act = torch.zeros((n_envs, n_a, 2), device=b.device)
+            b.timer_start()
+            for _ in range(steps):
+                b.step(act)
+            dev_ms = b.timer_stop() / steps
+            rec = {"workload": label, "ms_per_step": total_ms, "agent_steps_per_s": n_envs * n_a / (total_ms * 1e-3),
+                   "device_step_kernel_ms": dev_ms, "host_boundary_ms": total_ms - dev_ms,
+                   "what": "one C call per step: pinned action staging -> H2D -> k_env (f64 rows) -> k_export (widen + transpose on "
+                           "the device) -> ONE D2H into a pinned slot -> sync; host_boundary_ms = everything but the step kernel "
+                           "(incl. the caller's astype of the next action)"}
+            if n_envs == 1:
+                rec["reference_cpu_ms_per_step"] = lat.get("reference_cpu_n30_ms_per_step")
+            else:
+                blk = b.obs_dim * n_envs * n_a * 8 + 3 * n_envs * n_a * 8 + n_envs * n_a
+                rec["host_block_bytes"] = blk
+                rec["d2h_GBps_if_all_boundary_time_were_the_copy"] = blk / ((total_ms - dev_ms) * 1e-3) / 1e9
+            res.append(rec)
+            env.close()
+            del env
+        except Exception as ex:
+            res.append({"workload": label, "error": repr(ex)[:300]})
         torch.cuda.empty_cache()
     # (3) BASELINE config 0: the reference's own step (numpy glue + five native calls) at N = 8, native calls served by the
     #     reference's library on one host core vs by this library's legacy symbols (synchronous H2D / kernel / D2H per call)
@@ -575,7 +578,14 @@ def main():
     n_prewarm = prewarm(args.prewarm_ms)
     dt, kernel_ms = timed()
     dt = du.max_over_ranks(dt, device="cpu" if (args.rehearse_one_gpu or world == 1) else sb.device)
-    per_rank_us = du.gather_to_rank0(torch.tensor([kernel_ms * 1e3 / args.steps], dtype=torch.float64))
+    # (RCCL gathers device tensors, gloo host tensors)
+    coll_dev = "cpu" if (args.rehearse_one_gpu or world == 1) else sb.device
+    try:
+        per_rank_us = du.gather_to_rank0(torch.tensor([kernel_ms * 1e3 / args.steps], dtype=torch.float64, device=coll_dev))
+        per_rank_us = per_rank_us.cpu() if per_rank_us is not None else None
+    except Exception as ex:                            # an optional key must never cost the bench line
+        print(f"bench.py: per-rank gather failed: {ex!r}", file=sys.stderr)
+        per_rank_us = None
     in_shape = float(sb.indices(False, False)["in_flags"].float().mean().item())
     alg64 = sb.algorithmic_bytes_per_step()
     sb.close()
@@ -622,7 +632,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (state, every index / flag / reward decision) + f32 (obs, prior, action I/O, pre-filters)",
             "data": "synthetic", "prewarm_steps": n_prewarm,
-            "per_rank_kernel_us": per_rank_us.tolist(),
+            "per_rank_kernel_us": per_rank_us.tolist() if per_rank_us is not None else None,
             "config": {"workload": workload,
                        "agents": n_a, "envs_per_gpu": E, "envs_total": E * world, "obs_dtype": "f32",
                        "state_dtype": "f64", "in_shape_fraction": round(in_shape, 3), "seed": args.seed,

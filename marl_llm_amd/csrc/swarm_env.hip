@@ -434,7 +434,6 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             q[0] = (float)g.x; q[2] = (float)g.y;
         }
     }
-    if (sx == 0) { sp[at] = px; sp[AG + at] = py; sp[2 * AG + at] = vx; sp[3 * AG + at] = vy; }
     if (sx == 0) sflag[at] = 0;
     if constexpr (use_lat) {
         for (int q = tid; q < EPB * 64; q += T) {
@@ -445,11 +444,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         }
         if (sx == WPE - 1) reinterpret_cast<uint4 *>(pcr)[at] = uint4{0u, 0u, 0u, 0u};   // rows past lat_nrs stay empty
     }
-    // ---- forces + integration (split A).  For N <= 64 split A is ONE wavefront holding every agent of its environment(s):
-    // it parks the old positions in LDS for its own contact-spring loop (a wavefront's LDS operations execute in order,
-    // so no workgroup barrier is needed between its write and its read), integrates, and overwrites them with the new
-    // state -- the other splits meanwhile initialise LDS, and ONE barrier publishes everything.  For N > 64 split A
-    // spans several wavefronts and keeps the write / barrier / read / barrier / write / barrier sequence.
+    // ---- forces + integration (split A): wall spring / damper + the contact spring the previous pass left in sf_next,
+    // semi-implicit Euler; the other splits meanwhile initialise LDS, and ONE barrier publishes everything.
     double npx = px, npy = py, nvx = vx, nvy = vy;
     auto forces_integrate = [&]() {
         for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
@@ -487,42 +483,28 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     };
     auto publish_new_state = [&]() {
         sp[at] = npx; sp[AG + at] = npy; sp[2 * AG + at] = nvx; sp[3 * AG + at] = nvy;
-        if (act) {
+        if (DO_STEP && act) {                              // (the observation-only pass leaves the state as it is)
             P.p[sbase + i] = npx; P.p[sbase + n_a + i] = npy;
             P.dp[sbase + i] = nvx; P.dp[sbase + n_a + i] = nvy;
             if (copy_prior) store_nt(&reinterpret_cast<OT2 *>(a_prior)[(size_t)e * n_a + i], pri_now);
         }
     };
-    if constexpr (NW == 1) {
-        if (DO_STEP && sx == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // old positions (written above) before the reads below
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            STAMP(11);                                                    // (diagnostic builds: the state / action loads have landed)
-            // the whole workgroup waits for these ~100 instructions: issue them ahead of the CU's other waves (-1.5 %; the
-            // same for the wave with the longest lists in the list phase, or for every wave past it, gained nothing)
-            __builtin_amdgcn_s_setprio(3);
-            forces_integrate();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            publish_new_state();
-            __builtin_amdgcn_s_setprio(0);
-            STAMP(12);
-        }
-        __syncthreads();
-        STAMP(1);
-        EXIT_AT(0);
-    } else {
-        __syncthreads();
-        STAMP(1);
-        EXIT_AT(0);
-        if (DO_STEP) {
-            if (sx == 0) forces_integrate();
-            __syncthreads();                 // every lane is done with the old positions in LDS
-            if (sx == 0) publish_new_state();
-            __syncthreads();
-        }
+    // The contact spring came from the previous pass (sf_next), so the integration needs nobody else's position: split A goes
+    // from its loads straight to the new state and publishes it -- one barrier, for every N (round 2 parked the old
+    // positions in LDS for the contact loop: a wave barrier at N <= 64, two more workgroup barriers above).
+    if (sx == 0) {
+        STAMP(11);                                                        // (diagnostic builds: the state / action loads have landed)
+        // the whole workgroup waits for these ~100 instructions: issue them ahead of the CU's other waves (-1.5 %; the
+        // same for the wave with the longest lists in the list phase, or for every wave past it, gained nothing)
+        __builtin_amdgcn_s_setprio(3);
+        if (DO_STEP) forces_integrate();
+        publish_new_state();
+        __builtin_amdgcn_s_setprio(0);
+        STAMP(12);
     }
+    __syncthreads();
+    STAMP(1);
+    EXIT_AT(0);
     px = sp[at]; py = sp[AG + at];            // (the velocities are re-read from LDS where the prior policy needs them:
                                               // held in registers across the whole kernel they were spilled to scratch)
     STAMP(2);
@@ -539,6 +521,9 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // are OR-combined through LDS so that every lane ends up with its complete "nearby" masks (split B also with the
     // candidate masks)
     u64 nearbyN[NW], candN[NW], cand1N[NW], cand2N[NW], hitN[NW] = {};
+    // which split evaluates the contact spring of the next step: B, beside the others' walk (at N = 256 B's insertion over
+    // four 64-agent groups looks like the long pole in the stamps, but giving the spring to split A's walkers measured +1.5 %)
+    constexpr int CS = SB;
     {
         constexpr int JQ = JN / WPE;                  // agents j per split and 64-agent group
         static_assert(JQ * WPE == JN && JQ <= 32, "pair pass: JN must split evenly into <= 32 agents per split");
@@ -619,7 +604,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                 nearbyN[w] = pm[(0 * NW + w) * AG + at]; candN[w] = 0; cand1N[w] = 0; cand2N[w] = 0;
                 if (sx == SB) { candN[w] = pm[(1 * NW + w) * AG + at]; cand1N[w] = pm[(2 * NW + w) * AG + at]; cand2N[w] = pm[(4 * NW + w) * AG + at]; }
             }
-            if (sx == SB) {
+            if (sx == CS) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
                     hitN[w] = pm[(3 * NW + w) * AG + at];
@@ -749,12 +734,12 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         collision = dmin < P.c_avoid;
         snei[at * kNeiStride + kTopoMax] = (short)(collision ? 1 : 0);
     }
-    if (sx == SB) {
+    if (sx == CS) {
         // ---- ball-to-ball contact spring of the NEXT step: ENV:442-457 (_get_dist_b2b) + CPP:735-815 (_sf_b2b_all), on the
         // positions just published.  Entry (i,k) = collide * d_edge * k_ball * (-(delta/d_center)), delta = p_k - p_i (wrapped
         // when periodic), d_center un-wrapped for every pair the reference evaluates (its numpy wrap only touches agent 0's
         // row, which the i>j loop never reads); summed over k in index order (CPP:799-807).  The colliding pairs (centre
-        // distance < 2 size_a) are the contact masks of the pair pass.  Split B has the time: the other splits walk.
+        // distance < 2 size_a) are the contact masks of the pair pass.  (Which split: CS above.)
         double sfx = 0.0, sfy = 0.0;
         for (int rep = 0, reps = REPS(1); rep < reps; ++rep) {
             FENCE();
