@@ -186,6 +186,28 @@ __device__ __forceinline__ void pair_tests5(double d2u, double d2, double c_nb, 
         : "v"(d2u), "v"(d2), "s"(c_nb), "s"(c_hi), "s"(c_ht), "s"(c_cd), "s"(c_c1));
 }
 
+// The same with the sixth test of the N > 128 instantiations (the wider pre-selection ring) in the block: the test costs its
+// compare and its accumulation, no wait state.
+__device__ __forceinline__ void pair_tests6(double d2u, double d2, double c_nb, double c_hi, double c_ht, double c_cd, double c_c1, double c_c2,
+                                            unsigned &nb, unsigned &hi, unsigned &ht, unsigned &cd, unsigned &c1, unsigned &c2)
+{
+    unsigned long long m0, m1, m2, m3, m4, m5;
+    asm("v_cmp_lt_f64_e64 %6, %12, %14\n\t"
+        "v_cmp_lt_f64_e64 %7, %12, %15\n\t"
+        "v_cmp_lt_f64_e64 %8, %12, %16\n\t"
+        "v_cmp_lt_f64_e64 %9, %13, %17\n\t"
+        "v_cmp_lt_f64_e64 %10, %13, %18\n\t"
+        "v_cmp_lt_f64_e64 %11, %13, %19\n\t"
+        "v_addc_co_u32_e64 %0, %6, %0, %0, %6\n\t"
+        "v_addc_co_u32_e64 %1, %7, %1, %1, %7\n\t"
+        "v_addc_co_u32_e64 %2, %8, %2, %2, %8\n\t"
+        "v_addc_co_u32_e64 %3, %9, %3, %3, %9\n\t"
+        "v_addc_co_u32_e64 %4, %10, %4, %4, %10\n\t"
+        "v_addc_co_u32_e64 %5, %11, %5, %5, %11"
+        : "+v"(nb), "+v"(hi), "+v"(ht), "+v"(cd), "+v"(c1), "+v"(c2), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5)
+        : "v"(d2u), "v"(d2), "s"(c_nb), "s"(c_hi), "s"(c_ht), "s"(c_cd), "s"(c_c1), "s"(c_c2));
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
 template <typename F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
@@ -551,8 +573,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
                     if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
                     // nearby (CPP:161), its exception band, contact pairs of the NEXT step (ENV:442-457) on the un-wrapped
                     // distance; candidates (CPP:658) and close candidates on the wrapped one
-                    pair_tests5(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, nb, a_hi, ht, cd, c1);
-                    if constexpr (NW > 2) c2 = shl1_or_mask(c2, __ballot(d2 < P.c_close2));           // wider pre-selection ring (N > 128: pays there)
+                    if constexpr (NW > 2)         // with the wider pre-selection ring (N > 128: pays there)
+                        pair_tests6(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, P.c_close2, nb, a_hi, ht, cd, c1, c2);
+                    else
+                        pair_tests5(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, nb, a_hi, ht, cd, c1);
                 }
                 exc = exc || (a_hi != nb);             // some agent is not "nearby" by a hair (see the occupied-cell filter)
                 if constexpr (NPAD < 64) { a_nb[0] = nb; a_cd[0] = cd; a_c1[0] = c1; a_ht[0] = ht; }
@@ -1565,7 +1589,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // lists were shortest (A and C); the split with the longest lists (D) goes straight to its rows.
     prior_policy();
     if (obs != nullptr) {
-        head_blocks(NW == 1);                        // (N > 64: dealt over all splits but B -- the list phase is not the long pole there)
+        head_blocks(NW == 1);                        // (N > 64: dealt over all splits but B; the early A / C deal measured +15 % at N = 256)
         STAMP(9);
         EXIT_AT(11);
         sensed_rows(true, perm + (tid >> 6) * 64);

@@ -15,6 +15,8 @@ Usage:  MPLBACKEND=Agg python tests/golden/make_golden.py        (round-1 fixtur
         MPLBACKEND=Agg python tests/golden/make_golden.py r2     (round-2 fixtures: real shapes, thicker g2, reset
                                                                   statistics, learner-side modules)
         MPLBACKEND=Agg python tests/golden/make_golden.py r3     (round-3 fixtures: agent_strategy == 'llm')
+        MPLBACKEND=Agg python tests/golden/make_golden.py r3b    (round-3 fixtures: three episodes each of N = 30 / 100 / 200,
+                                                                  run by the tests as one 3-env batch)
 """
 import ctypes
 import os
@@ -311,8 +313,29 @@ def main_r3():
         print("g10_llm", n_a, "|u| max", np.abs(out["u"]).max(), "reward", out["rew"].sum((1, 2)))
 
 
+def main_r3_batch():
+    """Round-3 fixtures for BATCHES and the agent counts that are not powers of two: three independent reference
+    episodes (own seed, own randomly drawn target shape) for each of N = 30 (the reference's default, assembly_cfg.py:153),
+    100 and 200.  tests/test_gpu_parity.py::test_golden_batches runs the three episodes of one N as ONE 3-env batch with
+    ragged cell sets, so the batched claims rest on the reference itself, not only on the pinned oracle."""
+    gym, Wrapper = import_reference_env()
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    pkl = os.path.join(tmp, "results.pkl")
+    save_results(pkl, synthetic_shape_set())
+    rng = np.random.default_rng(2263)
+    for n_a, steps in ((30, 3), (100, 3), (200, 2)):
+        for s, (mode, warm) in enumerate((("random", 0), ("prior", 40), ("prior", 90))):
+            np.random.seed(3000 + 10 * n_a + s)
+            env = make_env(gym, Wrapper, n_a, pkl)
+            rec = record_episode(env, steps, mode, rng, warm)
+            np.savez_compressed(os.path.join(HERE, f"g11_n{n_a}_s{s}_{mode}.npz"), **rec)
+            print("g11", n_a, s, mode, "cells", rec["grid"].shape[1], "in shape", rec["in_flags"][-1].mean(), "reward", rec["rew"].sum((1, 2)))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "r2":
+    if len(sys.argv) > 1 and sys.argv[1] == "r3b":
+        main_r3_batch()
+    elif len(sys.argv) > 1 and sys.argv[1] == "r2":
         main_r2()
     elif len(sys.argv) > 1 and sys.argv[1] == "r3":
         main_r3()

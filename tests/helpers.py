@@ -8,8 +8,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_files(pattern=None):
-    """Recorded reference episodes: g2_* (synthetic shape set) and g6_* (the reference's own fig/*.png shapes)."""
-    pats = [pattern] if pattern else ["g2_*.npz", "g6_*.npz"]
+    """Recorded reference episodes: g2_* (synthetic shape set), g6_* (the reference's own fig/*.png shapes) and g11_* (three
+    episodes each of N = 30 / 100 / 200, also run as 3-env batches)."""
+    pats = [pattern] if pattern else ["g2_*.npz", "g6_*.npz", "g11_*.npz"]
     return sorted(f for p in pats for f in glob.glob(os.path.join(GOLDEN_DIR, p)))
 
 

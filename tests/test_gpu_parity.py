@@ -76,6 +76,43 @@ def test_golden_steps(path, dtype):
     sb.close()
 
 
+@pytest.mark.parametrize("n_a", [30, 100, 200])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_golden_batches(n_a, dtype):
+    """Three recorded reference episodes of one agent count (own seed, own target shape: ragged cell sets) teacher-forced
+    through the HIP path as ONE 3-env batch: the batched layout, env-indexed cell sets and the agent counts that are not
+    powers of two held against the reference itself (make_golden.py r3b), not only against the pinned oracle."""
+    zs = [load_golden(p) for p in golden_files(f"g11_n{n_a}_s*.npz")]
+    assert len(zs) == 3
+    E, T = len(zs), min(z["p"].shape[0] for z in zs)
+    cells, n_g = _pad_cells([z["grid"] for z in zs], max(z["grid"].shape[1] for z in zs))
+    assert len({float(z["r_avoid"]) for z in zs}) == 1 and len(set(n_g.tolist())) > 1
+    odt = torch.float64 if dtype == "f64" else torch.float32
+    sb = _batch(n_env=E, n_agents=n_a, n_cells_max=cells.shape[2], r_avoid=float(zs[0]["r_avoid"]), d_sen=float(zs[0]["d_sen"]),
+                obs_dtype=odt, boundary=tuple(zs[0]["boundary"]))
+    sb.set_cells(cells, n_g, [float(z["l_cell"]) for z in zs])
+    st = lambda k, t: np.stack([z[k][t] for z in zs])
+    for t in range(T):
+        sb.set_state(st("p", t), st("dp", t))
+        sb.observe()
+        assert np.array_equal(sb.indices(False, False)["neighbor_index"].cpu().numpy(), st("nei_prev", t))
+        act = torch.from_numpy(np.ascontiguousarray(st("a", t).transpose(0, 2, 1))).to(sb.device)      # (E,2,N) -> [E,N,2]
+        obs, rew, done, pri = sb.step(act)
+        p, dp = sb.get_state()
+        assert np.array_equal(p.cpu().numpy(), st("p_next", t)) and np.array_equal(dp.cpu().numpy(), st("dp_next", t))
+        idx = sb.indices()
+        for k_dev, k_ref in (("neighbor_index", "nei"), ("in_flags", "in_flags"), ("sensed_index", "sensed"), ("occupied_index", "occupied")):
+            assert np.array_equal(idx[k_dev].cpu().numpy(), st(k_ref, t)), (k_dev, t)
+        assert np.array_equal(rew.cpu().numpy().astype(np.float64), st("rew", t)[:, 0])
+        assert not done.any().item()
+        ref_obs = np.ascontiguousarray(st("obs", t).transpose(0, 2, 1)); ref_pri = np.ascontiguousarray(st("a_prior", t).transpose(0, 2, 1))
+        if dtype == "f32":
+            ref_obs = ref_obs.astype(np.float32); ref_pri = ref_pri.astype(np.float32)
+        assert np.array_equal(obs.cpu().numpy(), ref_obs)
+        assert np.array_equal(pri.cpu().numpy(), ref_pri)
+    sb.close()
+
+
 def test_known_answer_case():
     """SURVEY.md section 8c hand-checkable case (topo=2, G=4, OCC=5) through the HIP path."""
     z = load_golden(os.path.join(GOLDEN_DIR, "g1_kat_n3.npz"))
