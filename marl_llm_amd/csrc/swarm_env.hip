@@ -565,19 +565,32 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             for (int w = 0; w < NW; ++w) {
                 unsigned nb = 0, cd = 0, c1 = 0, ht = 0, c2 = 0, a_hi = 0;
                 const double *qx = spx + w * 64 + sx * JQ, *qy = spy + w * 64 + sx * JQ;
+                // (two agents j per 16-byte LDS read at an immediate offset -- as 8-byte reads the compiler pairs x with y in one
+                // stride-64 read whose address costs a vector add per pair; the periodic variant is a second copy of the loop,
+                // not a branch and a register copy per pair: 601 -> 574 us at 256 x 4096)
+                auto pairs = [&](auto per_c) {
+                    const bool PER = per_c;                              // a compile-time constant in the two copies of the lattice kernels
+                    static_assert(JQ % 2 == 0, "pair pass: two agents per LDS read");
 #pragma unroll
-                for (int q = 0; q < JQ; ++q) {
-                    double rx = qx[q] - px, ry = qy[q] - py;
-                    const double d2u = rx * rx + ry * ry;
-                    double d2 = d2u;
-                    if (P.periodic) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
-                    // nearby (CPP:161), its exception band, contact pairs of the NEXT step (ENV:442-457) on the un-wrapped
-                    // distance; candidates (CPP:658) and close candidates on the wrapped one
-                    if constexpr (NW > 2)         // with the wider pre-selection ring (N > 128: pays there)
-                        pair_tests6(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, P.c_close2, nb, a_hi, ht, cd, c1, c2);
-                    else
-                        pair_tests5(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, nb, a_hi, ht, cd, c1);
-                }
+                    for (int q = 0; q < JQ; q += 2) {
+                        const double2 x2 = *reinterpret_cast<const double2 *>(qx + q), y2 = *reinterpret_cast<const double2 *>(qy + q);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            double rx = (h ? x2.y : x2.x) - px, ry = (h ? y2.y : y2.x) - py;
+                            const double d2u = rx * rx + ry * ry;
+                            double d2 = d2u;
+                            if (PER) { wrap_rel(rx, ry, P.w_half, P.h_half); d2 = rx * rx + ry * ry; }
+                            // nearby (CPP:161), its exception band, contact pairs of the NEXT step (ENV:442-457) on the un-wrapped
+                            // distance; candidates (CPP:658) and close candidates on the wrapped one
+                            if constexpr (NW > 2)         // with the wider pre-selection ring (N > 128: pays there)
+                                pair_tests6(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, P.c_close2, nb, a_hi, ht, cd, c1, c2);
+                            else
+                                pair_tests5(d2u, d2, P.c_near, P.c_near_hi, P.c_ball, P.c_sen, P.c_close, nb, a_hi, ht, cd, c1);
+                        }
+                    }
+                };
+                if constexpr (LAT) { if (P.periodic) pairs(std::true_type{}); else pairs(std::false_type{}); }
+                else pairs(P.periodic != 0);                 // (the generic-scan kernels are beyond the instruction cache as it is: one copy)
                 exc = exc || (a_hi != nb);             // some agent is not "nearby" by a hair (see the occupied-cell filter)
                 if constexpr (NPAD < 64) { a_nb[0] = nb; a_cd[0] = cd; a_c1[0] = c1; a_ht[0] = ht; }
                 else if (rep == reps - 1) {
@@ -640,6 +653,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const u64 nearby1 = nearbyN[0];
     STAMP(15);
     EXIT_AT(2);
+    if (NW > 1 && sx == SB) __builtin_amdgcn_s_setprio(2);     // N > 64: B's insertion is a chain of dependent operations over four groups
+                                                                // of candidates -- issue it first, the walkers' independent work fills the gaps
     if (sx == SB) for (int rep = 0, reps = REPS(10); rep < reps; ++rep) {
         FENCE();
         bool collision = false;
@@ -786,6 +801,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         }
         if (act) P.sf_next[(size_t)e * n_a + i] = make_double2(sfx, sfy);
+        if (NW > 1) __builtin_amdgcn_s_setprio(0);
     }
     STAMP(3);
     EXIT_AT(3);
@@ -1415,6 +1431,10 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         // LPA lanes per agent, AGW agents per wave: split 0 takes the shortest lists, split 3 the longest
         ea = (at & ~63) + pw[(64 - ACTW) + sx * AGW + lane / LPA];
     }
+    // N > 64 (one workgroup per CU: nothing else fills a tail): no barrier follows, the workgroup ends with its slowest wave.
+    // Issue priority by the work that is left -- split D took the longest lists, C the next, B has the prior policy to run:
+    // 566 -> 550 us at 256 x 4096 (D 3 / C 2 / B 1 against 2/0/1, 3/1/2, 2/0/2: measured).
+    if (NW > 1) { if (sx == 3) __builtin_amdgcn_s_setprio(3); else if (sx == 2) __builtin_amdgcn_s_setprio(2); else if (sx == SB) __builtin_amdgcn_s_setprio(1); }
 
     // ---- (E) capped sensed list (CPP:236-271) + exploration-reward sums (CPP:494-551), fp32 fast path.  The kept list of
     // an agent is cut into four contiguous RANK ranges, one per lane of its quad; each lane walks its range bit by bit

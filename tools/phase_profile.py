@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SWARM_LIB"] = os.path.join(ROOT, "marl_llm_amd", "lib", "libswarmenv_stamps.so")
+os.environ["SWARM_LIB"] = os.environ.get("SWARM_STAMPS_LIB", os.path.join(ROOT, "marl_llm_amd", "lib", "libswarmenv_stamps.so"))
 
 import numpy as np
 import torch
