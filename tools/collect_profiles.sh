@@ -41,6 +41,7 @@ done
 python3 $R/tools/pmc_summary.py $OUT/final_pmc_summary.json 20 "assembly env, 64 agents x 4096 envs per GPU, assembled state" $CSVS > $OUT/pmc_print.txt
 rm -rf $OUT/pmc_*/
 python3 $R/tools/phase_profile.py 64 4096 > $OUT/per_role_stamps.txt 2>&1      # needs marl_llm_amd/lib/libswarmenv_stamps.so (build_lib(stamps=True))
+python3 $R/tools/phase_profile.py 256 4096 > $OUT/per_role_stamps_n256_e4096.txt 2>&1
 python3 $R/tools/ablate.py --cumulative > $OUT/cumulative_time.txt 2>&1
 echo "cumulative time done"
 export ABLATE_STEPS=10
