@@ -88,7 +88,8 @@ typedef struct swarm_config {
                                      * policy kernel of swarm_policy.h directly) */
     int32_t device;                 /* HIP device ordinal, -1 = current */
     int32_t debug_flags;            /* bit 0: force every exact (fp64) fallback path of the fp32 pre-filters; bit 1: disable the lattice path;
-                                     * bits 8..15: diagnostics (tools/ablate.py) */
+                                     * bit 2: a small batch keeps the full workgroup geometry (no half-occupied variant) -- results are
+                                     * identical with any of them; bits 8..15: diagnostics (tools/ablate.py) */
     double d_sen;                   /* assembly.py:199  = 0.4 */
     double r_avoid;                 /* assembly.py:124 */
     double size_a;                  /* assembly.py:44   = 0.035 */
