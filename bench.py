@@ -259,7 +259,10 @@ def measure(torch, n_a, E, state, steps, warmup, assemble_steps, seed, env_offse
     shapes = synthetic_shape_set() if shapes is None else shapes
     r_avoid = r_avoid_for(n_a, shapes)
     sy = synthetic_batch(E, n_a, shapes, seed=seed, env_offset=env_offset)
-    sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=r_avoid, device=device)
+    extra = {}
+    if os.environ.get("SWARM_BENCH_GMAX"):                 # diagnostic: another list length (LDS footprint / occupancy experiments)
+        extra["g_max"] = int(os.environ["SWARM_BENCH_GMAX"])
+    sb = SwarmBatch(n_env=E, n_agents=n_a, n_cells_max=sy["cells"].shape[2], r_avoid=r_avoid, device=device, **extra)
     sb.set_cells(sy["cells"], sy["n_g"], sy["l_cell"])
     sb.set_state(sy["p"], sy["dp"])
     sb.observe()

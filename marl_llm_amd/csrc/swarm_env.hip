@@ -259,12 +259,15 @@ template <int NPAD, bool HALF = false> struct Geo {
     static constexpr int WPE = 4;
     static constexpr int T = AG * WPE;
 #ifndef SWARM_WPS
-#define SWARM_WPS 6
+#define SWARM_WPS 7
 #endif
-    // waves per SIMD the register allocation aims for: six 4-wave workgroups per CU for N <= 64 (26.6 KB of LDS each in
-    // lattice mode); the N > 64 instantiations would spill at that budget
-    // (several environments per wavefront, N < 64: a few more live values -- five waves per SIMD rather than a spill)
-    static constexpr int WPS = NPAD == 64 ? SWARM_WPS : (NPAD < 64 ? 5 : 1);
+    // waves per SIMD the register allocation aims for.  N = 64, lattice kernels: SEVEN 4-wave workgroups per CU (<= 72 VGPRs --
+    // the allocator needs 65 -- and 22,976 B of LDS each: 18 of the CU's 128 allocation granules of 1280 B; the kernel loses
+    // 7 % from six to five workgroups per CU and gains 4 % from six to seven).  The generic-scan kernels and the N < 64
+    // geometries (several environments per wavefront: a few more live values) would spill there: six / five.  N > 64: one
+    // 16-wave workgroup per CU.
+    static constexpr int WPS_LAT = NPAD == 64 ? SWARM_WPS : (NPAD < 64 ? 5 : 1);
+    static constexpr int WPS_GEN = NPAD == 64 ? 6 : (NPAD < 64 ? 5 : 1);
 };
 
 constexpr double kSentinel = 1.0e200;     // coordinates of padding cells: d2 overflows to +inf
@@ -324,7 +327,7 @@ __device__ __forceinline__ float psi5_u_f32(float u)
 }
 
 template <int NPAD, typename OT, bool DO_STEP, bool LAT, bool HALF = false>
-__global__ void __launch_bounds__((Geo<NPAD, HALF>::T), (Geo<NPAD, HALF>::WPS))
+__global__ void __launch_bounds__((Geo<NPAD, HALF>::T), (LAT ? Geo<NPAD, HALF>::WPS_LAT : Geo<NPAD, HALF>::WPS_GEN))
 k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__restrict__ obs,
       float *__restrict__ reward, uint8_t *__restrict__ done, OT *__restrict__ a_prior)
 {
@@ -342,7 +345,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     unsigned *sbits = reinterpret_cast<unsigned *>(smem + P.off_sbits);  // [word][AG]
     unsigned *obits = reinterpret_cast<unsigned *>(smem + P.off_obits);  // [word][AG] (export launches only)
     short *sidx = reinterpret_cast<short *>(smem + P.off_sidx);          // [AG][g_stride]
-    int *part_c = reinterpret_cast<int *>(smem + P.off_partc);           // [WPE][AG] per-split nearest-cell candidates
+    typedef std::conditional_t<LAT, short, int> pc_t;                    // (lattice launches: 16-bit -- the kernel's LDS budget is seven workgroups per CU)
+    pc_t *part_c = reinterpret_cast<pc_t *>(smem + P.off_partc);         // [WPE][AG] per-split nearest-cell candidates (cell index < 2^15)
     u64 *pm = reinterpret_cast<u64 *>(smem + P.off_sidx);                // [WPE][2 or 3][NW][AG] partial pair masks (aliases sidx, earlier phase)
     unsigned *owords = reinterpret_cast<unsigned *>(smem + P.off_cmask); // [word][AG] occupied bits (NW == 1; aliases cmask)
     short *snei = reinterpret_cast<short *>(smem + P.off_snei);          // [AG][kTopoMax]
@@ -351,7 +355,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     u64 *lrm = reinterpret_cast<u64 *>(smem + P.off_lat);                // [EPB][64] lattice row masks
     short *lrs = reinterpret_cast<short *>(smem + P.off_lat + (size_t)EPB * 64 * 8);   // [EPB][64] row starts
     unsigned *cov = reinterpret_cast<unsigned *>(smem + P.off_cov);      // [EPB][ngw+1] cells within r_avoid/2 of ANY agent
-    int *sflag = reinterpret_cast<int *>(smem + P.off_flag);             // [AG] per-lane exception flags
+    int *sflag = reinterpret_cast<int *>(smem + P.off_flag);             // per-lane exception flags: generic launches [AG] ints; lattice launches one BYTE per agent thread (flag_* below)
     unsigned char *pc = smem + P.off_pc;                                 // [word][AG] kept-bit counts
     // row-space representation of the lattice path (LAT): window row t of agent thread `at` = lattice row b0 + t, its
     // columns are stored relative to the agent's first column ca0 (<= 17 columns are ever in range: 32-bit words)
@@ -371,6 +375,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // ordered insertion, reward combine) -- rotating spreads that over the four SIMDs of a CU.
     const int sx = __builtin_amdgcn_readfirstlane((tid / AG + (int)blockIdx.x) % WPE);
     const int aw = at >> 6;                  // which 64-agent group of the environment
+    auto flag_get = [&]() -> bool { return LAT ? ((reinterpret_cast<const unsigned *>(sflag)[at >> 2] >> ((at & 3) * 8)) & 1u) != 0 : (sflag[at] & 1) != 0; };
     const bool thr_on = NPAD >= 64 || at < ACTW;         // (half-occupied geometry: agent threads ACTW..63 hold nothing)
     const int el = (NPAD < 64 && thr_on) ? at / NPAD : 0;
     const int i = NPAD < 64 ? at % NPAD : at;
@@ -456,7 +461,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             q[0] = (float)g.x; q[2] = (float)g.y;
         }
     }
-    if (sx == 0) sflag[at] = 0;
+    if (sx == 0) { if constexpr (LAT) { if ((at & 3) == 0) sflag[at >> 2] = 0; } else sflag[at] = 0; }
     if constexpr (use_lat) {
         for (int q = tid; q < EPB * 64; q += T) {
             const int ek0 = blockIdx.x * EPB + (q >> 6);
@@ -608,7 +613,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             }
         }
         STAMP(14);
-        if (use_lat && exc) atomicOr(&sflag[at], 1);   // resolve the occupied-cell filter of this agent exactly
+        if (use_lat && exc) atomicOr(reinterpret_cast<unsigned *>(sflag) + (at >> 2), 1u << ((at & 3) * 8));   // resolve the occupied-cell filter of this agent exactly
         if constexpr (NPAD < 64) {
             // N < 64 (several environments per wavefront, JQ < 16): every split stores its partial masks, the readers OR the
             // WPE copies
@@ -1057,8 +1062,8 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
             if (unc_min) bc = bcd;
         }
     }
-    part_c[sx * AG + at] = bc;
-    double *part_d = reinterpret_cast<double *>(smem + P.off_partd);     // [WPE][AG] (lattice launches)
+    part_c[sx * AG + at] = (pc_t)bc;
+    double *part_d = reinterpret_cast<double *>(smem + P.off_partd);     // [WPE - 1][AG] (lattice launches; the list phase's `perm` reuses it)
     if constexpr (LAT) {
         // each walking split evaluates the exact distance of ITS candidate here, before the barrier (the gather overlaps the
         // other waves' walk); the merge behind the barrier then compares values that sit in LDS instead of every split
@@ -1066,7 +1071,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         if (sx != SB || WPE == 1) {
             const double2 g = cell64(bc);
             const double ex = g.x - px, ey = g.y - py;
-            part_d[sx * AG + at] = ex * ex + ey * ey;
+            part_d[(WPE > 1 && sx > SB ? sx - 1 : sx) * AG + at] = ex * ex + ey * ey;      // [walking split][AG]
         }
     }
     STAMP(16);
@@ -1083,7 +1088,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         if (LAT && WPE > 1 && s == SB) continue;                     // split B does not walk
         const int c = part_c[s * AG + at];
         double d;
-        if constexpr (LAT) d = part_d[s * AG + at];
+        if constexpr (LAT) d = part_d[(WPE > 1 && s > SB ? s - 1 : s) * AG + at];
         else { const double2 g = cell64(c); const double ex = g.x - px, ey = g.y - py; d = ex * ex + ey * ey; }
         if (d < best || (d == best && c < bc)) { best = d; bc = c; }
     }
@@ -1350,7 +1355,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     const LatEnv &L = P.lat[es];
     const u64 *rm = lrm + el * 64;
     const short *rs = lrs + el * 64;
-    const bool flg = (sflag[at] & 1) != 0;           // a pair within 1e-9 of the "nearby" threshold: exact occupied test
+    const bool flg = flag_get();                     // a pair within 1e-9 of the "nearby" threshold: exact occupied test
     for (int rep = 0, reps = REPS(4); rep < reps; ++rep) {
         FENCE();
         for (int t = sx; t < P.lat_nrs; t += WPE) {
@@ -1403,7 +1408,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
 
     // ---- (S) rank of every agent thread by (list length, index) inside its 64-group: each split compares against a quarter
     // of the group (the other agents' keys come from the wave's own lanes), the partial counts are summed through LDS
-    int *prk = part_c;                                   // [WPE][AG] (the nearest-cell candidates are consumed)
+    pc_t *prk = part_c;                                  // [WPE][AG] (the nearest-cell candidates are consumed)
     int n_kept;
     {
         const uint4 cq = reinterpret_cast<const uint4 *>(pcr)[at];
@@ -1412,7 +1417,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         int cnt = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) cnt += (__builtin_amdgcn_readlane(key, sx * 16 + q) < key) ? 1 : 0;
-        prk[sx * AG + at] = cnt;
+        prk[sx * AG + at] = (pc_t)cnt;
     }
     n_sel = n_kept > G ? G : n_kept;
     __syncthreads();
@@ -1724,7 +1729,7 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
     // The cap is rare (an agent deep inside a fine-celled shape): when no agent of this wave is capped -- the same
     // answer in all WPE splits, they hold the same agents -- ranks are slots and the rank-select bits are skipped.
     const bool any_sub = __any(n_kept > G) != 0;
-    int *sub_base = part_c;                  // [WPE][AG] first slot of each split's rank range, capped agents only (part_c is consumed)
+    int *sub_base = reinterpret_cast<int *>(smem + P.off_partc);   // [WPE][AG] first slot of each split's rank range, capped agents only (part_c is consumed)
     // (for N <= 64 `any_sub` is the same in every wave of the workgroup, so the barriers it guards are uniform)
     if (any_sub)
     for (int rep = 0, reps = REPS(5); rep < reps; ++rep) {
@@ -2484,19 +2489,20 @@ void layout_t(KP &k)
         // row-space lattice path: no per-cell bit sets at all
         constexpr int NRC = 16;
         k.off_hdr = take((size_t)AG * 16);
-        k.off_srow = take(max2((size_t)NRC * AG * 4, (size_t)NW * 1536));   // window-row words | scratch of the exact reward
+        k.off_srow = take(max2((size_t)(NRC - 1) * AG * 4, (size_t)NW * 1536));   // window-row words (lat_nrs <= 15 rows) | scratch of the exact reward
         k.off_pcr = take((size_t)AG * NRC);
         k.off_sidx = take(max2((size_t)AG * k.g_stride * 2, pm_bytes));      // sidx | pm
-        k.off_partc = take((size_t)WPE * AG * 4);                             // nearest-cell candidates | partial ranks
-        k.off_partd = take((size_t)WPE * AG * 8);                             // their exact squared distances
+        k.off_partc = take((size_t)WPE * AG * 2);                             // nearest-cell candidates | partial ranks (16-bit)
+        k.off_partd = take((size_t)(WPE - 1) * AG * 8);                       // the walking splits' exact squared distances | perm
         k.off_lat = take((size_t)EPB * 64 * (8 + 2));
         k.off_cov = take((size_t)EPB * 64 * 8);
-        k.off_flag = take((size_t)AG * 4);
+        k.off_flag = take((size_t)AG);                                        // one byte per agent thread
         k.off_snei = take((size_t)AG * kNeiStride * 2);
         k.off_sncf = take((size_t)AG * 4);
-        k.off_snear = take((size_t)NW * AG * 8);
-        k.off_perm = take((size_t)T);
-        k.off_rres = take((size_t)AG);
+        k.off_snear = take(NW > 1 ? (size_t)NW * AG * 8 : 0);                 // (N <= 64: the nearby mask stays in a register)
+        k.off_perm = k.off_partd;                                             // T bytes, written two barriers after the distances were consumed
+        static_assert((size_t)T <= (size_t)(WPE - 1) * AG * 8, "perm must fit the distance array it reuses");
+        k.off_rres = 0;
         k.smem_lat = (int)off;                           // lattice mode, no export
         k.off_orow = take((size_t)NRC * AG * 4);         // only launches that export the index scratch use it
         k.smem_lat_export = (int)off;
