@@ -261,12 +261,15 @@ template <int NPAD, bool HALF = false> struct Geo {
 #ifndef SWARM_WPS
 #define SWARM_WPS 7
 #endif
+#ifndef SWARM_WPS_SMALL
+#define SWARM_WPS_SMALL 6
+#endif
     // waves per SIMD the register allocation aims for.  N = 64, lattice kernels: SEVEN 4-wave workgroups per CU (<= 72 VGPRs --
     // the allocator needs 65 -- and 22,976 B of LDS each: 18 of the CU's 128 allocation granules of 1280 B; the kernel loses
-    // 7 % from six to five workgroups per CU and gains 4 % from six to seven).  The generic-scan kernels and the N < 64
-    // geometries (several environments per wavefront: a few more live values) would spill there: six / five.  N > 64: one
-    // 16-wave workgroup per CU.
-    static constexpr int WPS_LAT = NPAD == 64 ? SWARM_WPS : (NPAD < 64 ? 5 : 1);
+    // 7 % from six to five workgroups per CU and gains 4 % from six to seven).  N < 64 (several environments per wavefront:
+    // their lattice tables make it 19 - 21 granules): six (76 - 78 VGPRs, no scratch; 32 x 8192: 103.6 -> 97.0 us against
+    // five).  The generic-scan kernels: six / five.  N > 64: one 16-wave workgroup per CU.
+    static constexpr int WPS_LAT = NPAD == 64 ? SWARM_WPS : (NPAD < 64 ? SWARM_WPS_SMALL : 1);
     static constexpr int WPS_GEN = NPAD == 64 ? 6 : (NPAD < 64 ? 5 : 1);
 };
 
@@ -2568,7 +2571,7 @@ void set_lattice_mode(swarm_env *h, bool all_lattice, float rmax, float cmax, in
     {
         const int epb_full = h->npad < 64 ? 64 / h->npad : 1;
         const long long grid_full = ((long long)h->cfg.n_env + epb_full - 1) / epb_full;
-        h->half = k.lattice && h->npad < 64 && epb_full >= 2 && !(h->cfg.debug_flags & 4) && 2 * grid_full <= (long long)h->n_cu * 5;
+        h->half = k.lattice && h->npad < 64 && epb_full >= 2 && !(h->cfg.debug_flags & 4) && 2 * grid_full <= (long long)h->n_cu * 6;
     }
     layout(k, h->npad, h->half);
 }
