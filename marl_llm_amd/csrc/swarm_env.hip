@@ -268,8 +268,12 @@ template <int NPAD, bool HALF = false> struct Geo {
     // the allocator needs 65 -- and 22,976 B of LDS each: 18 of the CU's 128 allocation granules of 1280 B; the kernel loses
     // 7 % from six to five workgroups per CU and gains 4 % from six to seven).  N < 64 (several environments per wavefront:
     // their lattice tables make it 19 - 21 granules): six (76 - 78 VGPRs, no scratch; 32 x 8192: 103.6 -> 97.0 us against
-    // five).  The generic-scan kernels: six / five.  N > 64: one 16-wave workgroup per CU.
-    static constexpr int WPS_LAT = NPAD == 64 ? SWARM_WPS : (NPAD < 64 ? SWARM_WPS_SMALL : 1);
+    // five).  N = 128 (512 threads, ~47 KB of LDS): three workgroups per CU instead of two (80 VGPRs, 24 B of scratch;
+    // 128 x 4096: 218 -> 185 us).  The generic-scan kernels: six / five.  N = 256: one 16-wave workgroup per CU.
+#ifndef SWARM_WPS_128
+#define SWARM_WPS_128 6
+#endif
+    static constexpr int WPS_LAT = NPAD == 64 ? SWARM_WPS : (NPAD < 64 ? SWARM_WPS_SMALL : (NPAD == 128 ? SWARM_WPS_128 : 1));
     static constexpr int WPS_GEN = NPAD == 64 ? 6 : (NPAD < 64 ? 5 : 1);
 };
 
