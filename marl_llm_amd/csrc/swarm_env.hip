@@ -1443,10 +1443,11 @@ k_env(const KP P, const void *__restrict__ action, const int act_f64, OT *__rest
         // LPA lanes per agent, AGW agents per wave: split 0 takes the shortest lists, split 3 the longest
         ea = (at & ~63) + pw[(64 - ACTW) + sx * AGW + lane / LPA];
     }
-    // N > 64 (one workgroup per CU: nothing else fills a tail): no barrier follows, the workgroup ends with its slowest wave.
-    // Issue priority by the work that is left -- split D took the longest lists, C the next, B has the prior policy to run:
-    // 566 -> 550 us at 256 x 4096 (D 3 / C 2 / B 1 against 2/0/1, 3/1/2, 2/0/2: measured).
-    if (NW > 1) { if (sx == 3) __builtin_amdgcn_s_setprio(3); else if (sx == 2) __builtin_amdgcn_s_setprio(2); else if (sx == SB) __builtin_amdgcn_s_setprio(1); }
+    // No workgroup barrier follows: the workgroup ends with its slowest wave.  Issue priority by the work that is left -- split D
+    // took the longest lists, C the next, B has the prior policy to run (D 3 / C 2 / B 1 / A 0).  N = 256, one workgroup per CU
+    // and nothing else to fill a tail: 566 -> 550 us at 256 x 4096 (against 2/0/1: 558, 3/1/2: 555, 2/0/2: 561).  With seven
+    // workgroups per CU at N = 64 it still pays: 83.9 -> 83.3 us; 32 x 1024 (one workgroup generation): 25.0 -> 24.35 us.
+    { if (sx == 3) __builtin_amdgcn_s_setprio(3); else if (sx == 2) __builtin_amdgcn_s_setprio(2); else if (sx == SB) __builtin_amdgcn_s_setprio(1); }
 
     // ---- (E) capped sensed list (CPP:236-271) + exploration-reward sums (CPP:494-551), fp32 fast path.  The kept list of
     // an agent is cut into four contiguous RANK ranges, one per lane of its quad; each lane walks its range bit by bit
