@@ -47,7 +47,7 @@ int  swarm_policy_forward_explore(swarm_policy_t *p, const void *obs, int obs_is
 /* Arithmetic of the forward calls.  SWARM_POLICY_BF16 (default): operands rounded to bfloat16, fp32 sums -- the contract of
  * torch.autocast(bfloat16), ~4e-2 from the reference's fp32 actor on actions in [-1, 1].  SWARM_POLICY_BF16X3: operands split
  * into a high and a low bfloat16 part, three MFMAs per product (hi hi + hi lo + lo hi), fp32 sums -- within ~1e-4 of the fp32
- * actor (networks.py:6-44), about 2.5x the time. */
+ * actor (networks.py:6-44), about 1.9x the time. */
 #define SWARM_POLICY_BF16   0
 #define SWARM_POLICY_BF16X3 1
 int  swarm_policy_set_precision(swarm_policy_t *p, int precision);

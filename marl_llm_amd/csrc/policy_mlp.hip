@@ -35,7 +35,9 @@ typedef __attribute__((ext_vector_type(16))) float f16v;
 constexpr int kKP = 192;          // padded input / hidden width: 12 k-steps of 16, 6 feature tiles of 32
 constexpr int kKS = kKP / 16;     // k-steps per layer
 constexpr int kMT = kKP / 32;     // feature tiles per hidden layer
-constexpr int kWaves = 4;
+// wavefronts (32-row tiles) per workgroup = rows that share one pass of the weight stream.  bf16: four (eight: +3 %);
+// bf16x3 -- twice the weight stream -- eight (155 / 179 us on 262144 bf16 / fp32 rows instead of 200 / 221 with four)
+constexpr int waves_of(bool x3) { return x3 ? 8 : 4; }
 
 struct MlpParams {
     const bf8 *w1, *w2, *w3, *w4;          // packed fragments: [feature tile][k-step][lane] x 8 bf16
@@ -69,7 +71,7 @@ __device__ __forceinline__ int feat_of(int mt, int reg, int h) { return 32 * mt 
 // weights (bf16, as under torch.autocast), so no bias loads in the chain.
 constexpr int kChunkFrags = 3 * kKS;                                        // 36 fragments
 constexpr int kChunks = 7;                                                  // 2 per hidden layer + the output layer
-constexpr int kPre = kChunkFrags * 64 / (64 * kWaves);                      // 16-byte pieces per thread and chunk: 9
+constexpr int pre_of(int waves) { return (kChunkFrags * 64 + 64 * waves - 1) / (64 * waves); }   // 16-byte pieces per thread and chunk
 constexpr int kSmemBytes = 2 * kChunkFrags * 64 * 16;                       // 72 KB
 
 // TPW = row tiles (32 rows each) per wave.  With one tile every MFMA needs its own 1 KB weight-fragment read from LDS (four
@@ -80,9 +82,10 @@ constexpr int kSmemBytes = 2 * kChunkFrags * 64 * 16;                       // 7
 // fp32 actor to ~1e-4 instead of bf16's 4e-2.  The weight stream alternates high and low chunks (same chunk size, same two
 // LDS buffers: twice as many chunk steps); a high chunk meets both activation parts, a low chunk the high part only.
 template <bool IN_BF16, int TPW, bool X3>
-__global__ void __launch_bounds__(64 * kWaves, (TPW == 1 && !X3) ? 2 : 1)
+__global__ void __launch_bounds__(64 * waves_of(X3), (TPW == 1 && !X3) ? 2 : 1)
 k_policy_mlp(const MlpParams P, const void *__restrict__ obs_, float *__restrict__ act)
 {
+    constexpr int kWaves = waves_of(X3), kPre = pre_of(kWaves);
     extern __shared__ __align__(16) unsigned char smem_raw[];
     bf8 *const buf[2] = {reinterpret_cast<bf8 *>(smem_raw), reinterpret_cast<bf8 *>(smem_raw) + kChunkFrags * 64};
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -389,7 +392,8 @@ static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int6
     int tpw = 1;
     if (const char *ev = std::getenv("SWARM_POLICY_TPW")) tpw = ev[0] == '2' ? 2 : 1;
     if (p->precision == 1) tpw = 1;
-    const long long per_block = (long long)kWaves * 32 * tpw;
+    const int n_waves = waves_of(p->precision == 1);
+    const long long per_block = (long long)n_waves * 32 * tpw;
     const unsigned grid = (unsigned)((rows + per_block - 1) / per_block);
     if (!p->smem_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
@@ -400,7 +404,7 @@ static int policy_forward(swarm_policy_t *p, const void *obs, bool in_bf16, int6
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_policy_mlp<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
         p->smem_set = true;
     }
-    const dim3 g(grid), b(64 * kWaves);
+    const dim3 g(grid), b(64 * n_waves);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p->precision == 1) {
         if (in_bf16) hipLaunchKernelGGL((k_policy_mlp<true, 1, true>), g, b, kSmemBytes, st, q, obs, act);
