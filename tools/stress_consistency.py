@@ -27,10 +27,15 @@ def run(n_a, E, flags, steps, seed, frac, g_max=80):
     sb.close()
     return out
 ok = True
-for (n_a, E, steps, frac, g_max) in [(64, 2048, 40, 0.6, 80), (64, 1024, 25, 0.0, 80), (30, 2048, 30, 0.7, 80), (64, 512, 25, 0.8, 24), (128, 256, 12, 0.6, 80), (8, 2048, 30, 0.5, 80), (64, 256, 20, 0.8, 25)]:
-    ref = run(n_a, E, 0, steps, 7, frac, g_max)
+CASES = [(64, 2048, 40, 0.6, 80), (64, 1024, 25, 0.0, 80), (30, 2048, 30, 0.7, 80), (64, 512, 25, 0.8, 24), (128, 256, 12, 0.6, 80), (8, 2048, 30, 0.5, 80), (64, 256, 20, 0.8, 25)]
+SEED = 7
+if "--extended" in sys.argv:      # the other workgroup geometries (N = 16, 100, 200, 256; the half-occupied one: 32 x 256) and another seed
+    CASES = [(256, 96, 10, 0.6, 80), (200, 64, 10, 0.7, 80), (100, 256, 15, 0.6, 80), (16, 2048, 30, 0.6, 80), (32, 256, 30, 0.7, 80), (64, 4096, 30, 0.7, 80), (128, 512, 12, 0.3, 80)]
+    SEED = 11
+for (n_a, E, steps, frac, g_max) in CASES:
+    ref = run(n_a, E, 0, steps, SEED, frac, g_max)
     for flags in (1, 2, 3):
-        got = run(n_a, E, flags, steps, 7, frac, g_max)
+        got = run(n_a, E, flags, steps, SEED, frac, g_max)
         same = all(torch.equal(a, b) for a, b in zip(ref, got))
         ok &= same
         print(f"N={n_a} E={E} steps={steps} frac={frac} G={g_max} flags={flags}: {'identical' if same else 'MISMATCH'}  reward sum {ref[1].sum().item():.0f}", flush=True)
